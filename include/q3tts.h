@@ -1,0 +1,154 @@
+/*
+ * q3tts.h -- C ABI of the MI355X-native Qwen3-TTS engine ("Boundary B").
+ *
+ * This is what the reference's `src/tts` layer binds instead of llama.cpp + ONNX Runtime:
+ *   q3tts_engine_create      <- TtsEngine::new                (/root/reference/src/tts/engine.rs:84-169)
+ *   q3tts_generate_batch     <- TtsEngine::run_inference_stream (engine.rs:445-656), batched over requests
+ *   q3tts_prompt_*           <- PromptBuilder::{build_core, build_clone_prompt} (src/tts/prompt.rs:28-277)
+ *   q3tts_sampler_*          <- LlamaSampler::{new, greedy, sample} (src/models/llama/mod.rs:627-776)
+ *   q3tts_chunker_*          <- decoder-thread chunker (engine.rs:495-543)
+ *   q3tts_decoder_*          <- AudioDecoder::{load, create_state, decode} (src/models/onnx.rs:324-496)
+ *   q3tts_assets_*           <- Assets::{load, project, get_codec_embedding, get_text_embedding} (src/assets_manager.rs)
+ *   q3tts_mel                <- SpeakerEncoder::compute_mel (src/models/onnx.rs:167-320)
+ * "Boundary A", the 28 llama_* symbols the unmodified reference dlopens, is declared in q3tts_llama.h.
+ *
+ * Rules: plain pointers and sizes, caller-owned buffers, int status (0 = ok, like llama_decode), no
+ * exceptions/aborts across the ABI; q3tts_last_error() returns the thread's last message.
+ * The HIP path is the only path: with no usable GPU the compute entry points return an error.
+ */
+#ifndef Q3TTS_H
+#define Q3TTS_H
+#include <stdint.h>
+#include <stddef.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define Q3TTS_OK 0
+#define Q3TTS_ERR -1
+
+const char* q3tts_last_error(void);
+int q3tts_version(void);
+int q3tts_device_count(void); /* visible HIP devices (0 when none) */
+
+/* ---- SamplerConfig (engine.rs:13-45) ---- */
+typedef struct q3tts_sampler_config {
+    float temperature; /* default 0.7, <= 0 = greedy */
+    int32_t top_k;     /* default 40, 0 = disabled   */
+    float top_p;       /* default 0.9, 1.0 = disabled */
+    int32_t has_seed;  /* 0 => wall-clock nanoseconds (engine.rs:473-478) */
+    uint64_t seed;
+} q3tts_sampler_config;
+void q3tts_sampler_config_default(q3tts_sampler_config* c);
+
+/* ---- engine ---- */
+typedef struct q3tts_engine q3tts_engine;
+typedef struct q3tts_engine_params {
+    const char* model_dir; /* holds gguf*, onnx/ (engine.rs:91-124) */
+    const char* quant;     /* "q8_0" | "q5_k_m" | "none" ... */
+    int32_t device;        /* HIP device ordinal */
+    int32_t max_batch;     /* lock-stepped sequences per step */
+    int32_t max_prompt;    /* <= 1024 (reference's effective cap, llama/mod.rs:567-581) */
+    int32_t max_steps;     /* default 512 (engine.rs:152) */
+    int32_t load_codec;    /* 0: codes only */
+    int32_t use_graph;     /* 1: hipGraph frame replay */
+} q3tts_engine_params;
+void q3tts_engine_params_default(q3tts_engine_params* p);
+int q3tts_engine_create(const q3tts_engine_params* p, q3tts_engine** out);
+void q3tts_engine_destroy(q3tts_engine* e);
+
+typedef struct q3tts_request {
+    const float* prompt;   /* [n_prompt][2048] f32 embedding rows (PromptData.embd) */
+    int32_t n_prompt;
+    q3tts_sampler_config sampler;
+    int32_t max_steps;
+    int32_t mask_eos;      /* test/bench knob: never emit EOS (fixed-length runs) */
+    int32_t* codes_out;    /* capacity max_steps*16 */
+    float* pcm_out;        /* capacity pcm_capacity floats (may be NULL) */
+    int64_t pcm_capacity;
+    /* results */
+    int32_t n_frames;
+    int64_t n_pcm;
+    double prefill_ms, first_chunk_ms, total_ms;
+} q3tts_request;
+/* runs all requests to completion in lock step (request-level batching) */
+int q3tts_generate_batch(q3tts_engine* e, q3tts_request* reqs, int32_t n_reqs, int32_t want_pcm);
+
+typedef struct q3tts_stats {
+    double frame_loop_ms; int64_t frames; double prefill_ms;
+    double gemv_ms; int64_t gemv_launches; double gemv_bytes; /* instrumented leg only */
+    double codec_ms; int64_t codec_calls;
+    double talker_weight_bytes, predictor_weight_bytes, kv_bytes_per_token;
+} q3tts_stats;
+int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* out);
+void q3tts_engine_reset_stats(q3tts_engine* e);
+void q3tts_engine_set_instrument(q3tts_engine* e, int32_t on);
+double q3tts_engine_bytes_per_step(q3tts_engine* e, int32_t batch, double mean_ctx);
+
+/* ---- assets + prompt builder (host) ---- */
+typedef struct q3tts_assets q3tts_assets;
+int q3tts_assets_open(const char* gguf_path, q3tts_assets** out);
+void q3tts_assets_close(q3tts_assets* a);
+const q3tts_assets* q3tts_engine_assets(q3tts_engine* e);
+int q3tts_assets_codec_embedding(const q3tts_assets* a, int32_t q, int32_t code, float* out2048);
+int q3tts_assets_text_embedding(const q3tts_assets* a, int64_t token, float* out2048);
+int q3tts_assets_tts_pad(const q3tts_assets* a, float* out2048);
+/* returns rows written (each 2048 f32) or <0; lang_id/spk_id < 0 mean None; pointers may be NULL */
+int q3tts_prompt_build_core(const q3tts_assets* a, const int32_t* text_ids, int32_t n_text, int32_t lang_id, int32_t spk_id,
+                            const float* spk_emb2048, const int32_t* instr_ids, int32_t n_instr, const float* mid_rows,
+                            int32_t n_mid, float* out, int32_t max_rows);
+int q3tts_prompt_build_clone(const q3tts_assets* a, const int32_t* text_ids, int32_t n_text, const int32_t* ref_codes,
+                             int32_t n_ref_codes, const int32_t* ref_text_ids, int32_t n_ref_text, const float* spk_emb2048,
+                             int32_t lang_id, const int32_t* instr_ids, int32_t n_instr, float* out, int32_t max_rows);
+
+/* ---- sampler (host) ---- */
+typedef struct q3tts_sampler q3tts_sampler;
+q3tts_sampler* q3tts_sampler_new(float temperature, int32_t top_k, float top_p, uint64_t seed);
+void q3tts_sampler_free(q3tts_sampler* s);
+int32_t q3tts_sampler_sample(q3tts_sampler* s, const float* logits, int32_t n_vocab, int32_t start, int32_t end);
+
+/* ---- chunker (host) ---- */
+typedef void (*q3tts_decode_cb)(void* user, const int64_t* codes, int32_t n_codes, int32_t is_final);
+typedef struct q3tts_chunker q3tts_chunker;
+q3tts_chunker* q3tts_chunker_new(q3tts_decode_cb cb, void* user);
+void q3tts_chunker_free(q3tts_chunker* c);
+int q3tts_chunker_push(q3tts_chunker* c, const int64_t* codes, int32_t n, int32_t is_final);
+
+/* ---- streaming codec decoder (device) ---- */
+typedef struct q3tts_decoder q3tts_decoder;
+int q3tts_decoder_create(const char* codec_gguf, int32_t n_streams, q3tts_decoder** out);
+void q3tts_decoder_destroy(q3tts_decoder* d);
+int q3tts_decoder_samples_per_frame(q3tts_decoder* d);
+int q3tts_decoder_reset(q3tts_decoder* d, int32_t stream);
+/* codes [n_frames][16] i64; writes up to n_frames*samples_per_frame floats; *valid_samples = prefix to keep */
+int q3tts_decoder_decode(q3tts_decoder* d, int32_t stream, const int64_t* codes, int32_t n_frames, int32_t is_last,
+                         float* final_wav, int64_t* valid_samples);
+
+/* ---- mel front end (device) ---- */
+int q3tts_mel_frames(int32_t n_samples);
+int q3tts_mel(const float* audio, int32_t n_samples, float* mel_out /* [frames][128] */);
+
+/* ---- transformer contexts (shared with the llama shim; also the layer-level parity surface) ---- */
+typedef struct q3tts_tf q3tts_tf;
+int q3tts_tf_open(const char* gguf_path, int32_t n_ctx, int32_t max_tok, q3tts_tf** out);
+void q3tts_tf_close(q3tts_tf* t);
+int q3tts_tf_dims(q3tts_tf* t, int32_t* n_embd, int32_t* n_layer, int32_t* n_head, int32_t* n_vocab);
+void q3tts_tf_clear(q3tts_tf* t);
+/* ntok tokens of one sequence: x [ntok][n_embd]; pos [ntok][4]; appends to the KV cache.
+ * hidden_out [ntok][n_embd] (final-norm) and logits_out [ntok][row1-row0] may be NULL. */
+int q3tts_tf_eval(q3tts_tf* t, const float* x, const int32_t* pos4, int32_t ntok, float* hidden_out, float* logits_out,
+                  int32_t row0, int32_t row1);
+
+/* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
+int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,
+                     const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);
+int q3tts_op_rmsnorm_quant(const float* x, const float* g, int32_t d, int32_t ntok, float eps, int8_t* xq, uint16_t* xd,
+                           float* xn);
+int q3tts_op_swiglu_quant(const float* gu, int32_t ff, int32_t ntok, int8_t* aq, uint16_t* ad);
+int q3tts_op_argmax(const float* logits, int32_t n, int32_t start, int32_t end, int32_t mask_idx, int32_t* out);
+int q3tts_op_project(const float* x, const float* w /* [n_out][n_in] */, const float* b, int32_t n_in, int32_t n_out, float* y);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

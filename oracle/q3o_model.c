@@ -146,13 +146,15 @@ static void attn_head(const float* q, const uint16_t* K, const uint16_t* V, size
         }
         float lc = part[0];
         float oc[128];
-        for (int d = 0; d < 128; d++) {
-            float S[4] = { 0, 0, 0, 0 };
+        for (int d = 0; d < 128; d++) { /* 16 interleaved chains r = j mod 16, fixed combine tree */
+            float S[16] = { 0 };
             for (int j = 0; j < cn; j++) {
                 float v = q3_f16_to_f32(V[(size_t)(c0 + j) * stride + d]);
-                S[j & 3] = q3_fmaf(p[j], v, S[j & 3]);
+                S[j & 15] = q3_fmaf(p[j], v, S[j & 15]);
             }
-            oc[d] = (S[0] + S[1]) + (S[2] + S[3]);
+            float T4[4];
+            for (int w = 0; w < 4; w++) T4[w] = (S[4 * w] + S[4 * w + 1]) + (S[4 * w + 2] + S[4 * w + 3]);
+            oc[d] = (T4[0] + T4[1]) + (T4[2] + T4[3]);
         }
         if (c0 == 0) {
             M = mc; L = lc; memcpy(O, oc, sizeof(O));

@@ -1,0 +1,21 @@
+#!/bin/bash
+# Builds libq3tts.so (HIP kernels + C ABI, both boundaries) in-tree for gfx950.  No cmake: plain hipcc.
+set -e
+cd "$(dirname "$0")"
+ARCH=${Q3_ARCH:-gfx950}
+FLAGS="-O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
+mkdir -p build
+OBJS=""
+for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/llama_shim.cpp; do
+  [ -f "$f" ] || continue
+  o=build/$(basename "$f").o
+  if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then
+    echo "hipcc $f"
+    /opt/rocm/bin/hipcc $FLAGS -x hip -c "$f" -o "$o" &
+  fi
+  OBJS="$OBJS $o"
+done
+wait
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=$ARCH -o libq3tts.so $OBJS
+mkdir -p runtime && cp -f libq3tts.so runtime/libllama.so
+echo "built $(pwd)/libq3tts.so"

@@ -1,0 +1,98 @@
+// capi_ops.cpp -- kernel-level C-ABI entry points for the parity tests (host buffers in, host buffers out).
+#include "../../include/q3tts.h"
+#include "transformer.h"
+
+using namespace q3;
+#define Q3_API_BEGIN try {
+#define Q3_API_END(failval) } catch (const std::exception& ex) { set_last_error(ex.what()); return failval; } catch (...) { set_last_error("unknown error"); return failval; }
+static void require_gpu() {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess || n <= 0) throw Error("no HIP device available: the HIP path is the only compute path (no CPU fallback)");
+}
+
+extern "C" {
+
+int q3tts_op_gemv_q8(const void* w, int32_t n, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok, float* y, int32_t lpr) {
+    Q3_API_BEGIN
+    require_gpu();
+    DevBuf<uint8_t> storage;
+    Q8Mat m = q8mat_from_host(w, n, k, storage);
+    DevBuf<int8_t> dxq((size_t)ntok * k); dxq.upload(xq, dxq.n);
+    DevBuf<uint16_t> dxd((size_t)ntok * (k / 32)); dxd.upload(xd, dxd.n);
+    const int nsseg = ((k >> 8) + 7) / 8;
+    DevBuf<float> parts((size_t)nsseg * ntok * n);
+    launch_gemv_q8(0, m, 0, n, dxq.p, dxd.p, parts.p, n, ntok, lpr);
+    Q3_HIP(hipDeviceSynchronize());
+    std::vector<float> hp(parts.n);
+    parts.download(hp.data(), hp.size());
+    for (int t = 0; t < ntok; t++)
+        for (int r = 0; r < n; r++) { // spec S3: super-segment sums added in order
+            float v = hp[((size_t)0 * ntok + t) * n + r];
+            for (int s = 1; s < nsseg; s++) v = v + hp[((size_t)s * ntok + t) * n + r];
+            y[(size_t)t * n + r] = v;
+        }
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+int q3tts_op_rmsnorm_quant(const float* x, const float* g, int32_t d, int32_t ntok, float eps, int8_t* xq, uint16_t* xd, float* xn) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(d % 256 == 0 && d <= 2048, "d must be a multiple of 256 and <= 2048");
+    DevBuf<float> dx((size_t)ntok * d), dg(d), dxn((size_t)ntok * d);
+    dx.upload(x, dx.n); dg.upload(g, d);
+    DevBuf<int8_t> dq((size_t)ntok * d); DevBuf<uint16_t> dd((size_t)ntok * d / 32);
+    NormArgs a{};
+    a.h_in = dx.p; a.h_stride = d; a.g = dg.p; a.eps = eps; a.d = d; a.xq = dq.p; a.xd = dd.p; a.xn_out = dxn.p;
+    launch_rmsnorm_quant(0, a, ntok);
+    Q3_HIP(hipDeviceSynchronize());
+    if (xq) dq.download(xq, dq.n);
+    if (xd) dd.download(xd, dd.n);
+    if (xn) dxn.download(xn, dxn.n);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+int q3tts_op_swiglu_quant(const float* gu, int32_t ff, int32_t ntok, int8_t* aq, uint16_t* ad) {
+    Q3_API_BEGIN
+    require_gpu();
+    DevBuf<float> dgu((size_t)ntok * 2 * ff); dgu.upload(gu, dgu.n);
+    DevBuf<int8_t> dq((size_t)ntok * ff); DevBuf<uint16_t> dd((size_t)ntok * ff / 32);
+    launch_swiglu_quant(0, dgu.p, ff, dq.p, dd.p, ntok);
+    Q3_HIP(hipDeviceSynchronize());
+    dq.download(aq, dq.n); dd.download(ad, dd.n);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+int q3tts_op_argmax(const float* logits, int32_t n, int32_t start, int32_t end, int32_t mask_idx, int32_t* out) {
+    Q3_API_BEGIN
+    require_gpu();
+    DevBuf<float> dl(n); dl.upload(logits, n);
+    DevBuf<int32_t> dm(1), dout(1);
+    dm.upload(&mask_idx, 1);
+    launch_argmax(0, dl.p, n, start, end, dm.p, dout.p, 1, 0, 1);
+    Q3_HIP(hipDeviceSynchronize());
+    dout.download(out, 1);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+int q3tts_op_project(const float* x, const float* w, const float* b, int32_t n_in, int32_t n_out, float* y) {
+    Q3_API_BEGIN
+    require_gpu();
+    std::vector<float> wt((size_t)n_in * n_out);
+    for (int o = 0; o < n_out; o++) for (int i = 0; i < n_in; i++) wt[(size_t)i * n_out + o] = w[(size_t)o * n_in + i];
+    DevBuf<float> dx(n_in), dw(wt.size()), db(n_out), dy(n_out);
+    dx.upload(x, n_in); dw.upload(wt.data(), wt.size()); db.upload(b, n_out);
+    launch_project(0, dx.p, n_in, dw.p, db.p, n_in, n_out, dy.p, n_out, 1);
+    Q3_HIP(hipDeviceSynchronize());
+    dy.download(y, n_out);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+int q3tts_mel(const float*, int32_t, float*) { set_last_error("mel kernel not built yet"); return Q3TTS_ERR; }
+int q3tts_mel_frames(int32_t n) { const int plen = n + 768; return (plen > 1024 ? plen - 1024 : 0) / 256 + 1; }
+
+} // extern "C"

@@ -1,0 +1,24 @@
+// codec.h -- streaming codec decoder on device (codes -> 24 kHz PCM), the replacement for the ONNX AudioDecoder
+// (/root/reference/src/models/onnx.rs:324-496).  Architecture "Q3TTS-codec-synth" (oracle/q3o_codec.c).
+#pragma once
+#include "q3_common.h"
+#include <memory>
+#include <string>
+
+namespace q3 {
+
+class CodecDecoder {
+public:
+    CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call);
+    ~CodecDecoder();
+    int samples_per_frame() const;
+    void reset(int stream); // AudioDecoder::create_state (onnx.rs:338-340, 474-495)
+    // codes: host [n_frames][16] (already clamped to [0,2047], engine.rs:515-519); pcm: host, n_frames*spf floats
+    int decode(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm);
+    double flops_per_frame() const;
+private:
+    struct Impl;
+    std::unique_ptr<Impl> impl_;
+};
+
+} // namespace q3

@@ -1,0 +1,94 @@
+// kernels.h -- launch API of the hand-written gfx950 kernels for the AR decode path.
+// Every kernel implements the arithmetic of include/q3tts_spec.h exactly (bit-identical to oracle/).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdint>
+
+namespace q3 {
+
+// Q8_0 matrix repacked for coalesced 1-KiB wave loads (see weights.cpp / DESIGN.md "HBM layout"):
+//   qs : [N/32][K/32][2 halves][32 rows][16 B]   int8 quants, one 1-KiB tile per (row-group, block)
+//   sc : [N/32][K/256][32 rows][8]               f16 block scales, one 16-B vector per (row, segment)
+struct Q8Mat {
+    const uint8_t* qs = nullptr;
+    const uint16_t* sc = nullptr;
+    int N = 0;      // logical rows
+    int Npad = 0;   // rows padded to 32
+    int K = 0;
+    size_t bytes() const { return (size_t)Npad * K + (size_t)Npad * (K / 32) * 2; }
+};
+
+// Per-token routing for batched steps (one entry per token row of the activation matrix)
+struct TokMeta {
+    const int32_t* seq;    // [ntok] sequence slot (page-table row)
+    const int32_t* slot;   // [ntok] cache position this token is written to (= #cached before it)
+    const int32_t* pos;    // [ntok][4] M-RoPE position streams (engine.rs:306-314)
+};
+
+struct KvCache {           // paged f16 KV cache (pages of 64 positions)
+    uint16_t* k;           // [page][layer][kvh][16 dchunks][64 pos][8]
+    uint16_t* v;           // [page][layer][kvh][64 pos][128]
+    const int32_t* page_table; // [n_seq][max_pages]
+    int max_pages;
+    int n_layer, n_kv;
+    __host__ __device__ size_t page_stride() const { return (size_t)n_layer * n_kv * 8192; } // halfs per page (per K or V)
+    __host__ __device__ size_t layer_stride() const { return (size_t)n_kv * 8192; }
+};
+
+// out[(sseg*ntok + tok)*out_stride + r] = super-segment partial of row (row0+r) . x[tok]      (spec S3)
+void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
+                    float* out, int out_stride, int ntok, int lpr_hint = 0);
+
+// h = h_in (+ sum of nparts partial slabs, in order); optional store h_out; xn = rmsnorm(h)*g (spec S4);
+// quantise to int8 blocks (spec S2).  h_in may be indirect: row idx[tok] of a table (idx != nullptr).
+struct NormArgs {
+    const float* h_in; int h_stride;            // [ntok][h_stride]
+    const int32_t* idx; int idx_stride;         // optional: h row = h_in + idx[tok*idx_stride]*h_stride
+    const float* parts; int nparts; int parts_stride; // [p][ntok][parts_stride]
+    float* h_out;                               // optional [ntok][d]
+    const float* g; float eps; int d;
+    int8_t* xq; uint16_t* xd;                   // [ntok][d], [ntok][d/32]
+    float* xn_out;                              // optional [ntok][d] (final-norm hidden)
+};
+void launch_rmsnorm_quant(hipStream_t st, const NormArgs& a, int ntok);
+
+// per-head q/k RMSNorm + NeoX M-RoPE; q -> qrot f32; k,v -> f16 paged cache (spec S4',S5,S6)
+void launch_qk_rope_append(hipStream_t st, const float* qkv, int qkv_stride, const float* parts_unused, int n_head, int n_kv,
+                           const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos,
+                           const float* rope_sin, int n_ctx, const int32_t* mrope_sec /*device [4]*/, const TokMeta& tm,
+                           const KvCache& kv, int layer, float* qrot, int ntok);
+
+// causal GQA attention over the paged cache (spec S7) + int8 quantisation of the output
+void launch_attention(hipStream_t st, const float* qrot, int n_head, int n_kv, const TokMeta& tm, const KvCache& kv,
+                      int layer, float* att /*optional [ntok][n_head*128]*/, int8_t* aq, uint16_t* ad, int ntok);
+
+// a = silu(g)*u over gate/up slabs, quantise (spec S8,S2). gu layout: [ntok][2*ff] with gate first.
+void launch_swiglu_quant(hipStream_t st, const float* gu, int ff, int8_t* aq, uint16_t* ad, int ntok);
+
+// first-max argmax over logits[tok][start..end) with strict '>' (llama/mod.rs:690-701); mask index -> -inf
+void launch_argmax(hipStream_t st, const float* logits, int stride, int start, int end, const int32_t* mask_per_tok,
+                   int32_t* out, int out_stride, int add, int ntok);
+
+// assets_manager.rs:383-399 : out[o] = b[o] + sum_i x[i]*Wt[i][o]  (mul then add, ascending i). Wt is [n_in][n_out].
+void launch_project(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
+                    float* out, int out_stride, int ntok);
+// batched form over table rows, used once at load to pre-project the codec tables (same arithmetic)
+void launch_project_table(hipStream_t st, const float* table, int64_t rows, const float* Wt, const float* b, int n_in,
+                          int n_out, float* out);
+
+// engine.rs:622-631 : fb = (((0 + E0[c0]) + E1[c1]) ... + E15[c15]) + tts_pad
+void launch_feedback(hipStream_t st, const float* const* tables /*device [16]*/, const int64_t* table_rows /*device[16]*/,
+                     const int32_t* codes, int codes_stride, const float* tts_pad, float* out, int ntok);
+
+void launch_gather_rows(hipStream_t st, const float* table, int64_t rows, const int32_t* idx, int idx_stride, int row_len,
+                        float* dst, int ntok);
+
+struct AdvanceArgs {
+    int B; int32_t *finished, *n_frames; const int32_t* max_frames; const int32_t* cur_codes; int32_t* hist; int hist_stride;
+    int32_t *t_slot, *t_pos;
+};
+void launch_advance(hipStream_t st, const AdvanceArgs& a);
+
+void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
+
+} // namespace q3

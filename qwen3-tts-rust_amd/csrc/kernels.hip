@@ -1,0 +1,556 @@
+// kernels.hip -- hand-written gfx950 (CDNA4, wave64) kernels for the Qwen3-TTS autoregressive decode path.
+//
+// Replaces what the reference reaches through llama_decode (/root/reference/src/models/llama/mod.rs:442-451)
+// and its own CPU glue (assets_manager.rs:383-399 project, engine.rs:622-631 feedback, llama/mod.rs:690-701
+// argmax).  All arithmetic follows include/q3tts_spec.h so results are bit-identical to oracle/.
+//
+// These are HBM/L2-bound integer-dot + small-reduction kernels: the design rules that matter are
+// 16-B-per-lane coalesced weight streams (1 KiB per wave instruction), all of a wave's weight loads issued
+// before first use, wave-shuffle reductions, and >=256 workgroups per launch.  No MFMA here on purpose.
+#include "kernels.h"
+#include "../../include/q3tts_spec.h"
+
+namespace q3 {
+
+__device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
+__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+__device__ __forceinline__ float wave_sum_bfly(float v) { // spec butterfly: xor 32,16,8,4,2,1
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
+    return v;
+}
+__device__ __forceinline__ float wave_max_bfly(float v) {
+#pragma unroll
+    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    return v;
+}
+__device__ __forceinline__ int dot16(const uint4& a, const uint4& b) {
+    int s = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, 0, false);
+    s = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, s, false);
+    s = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, s, false);
+    s = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, s, false);
+    return s;
+}
+__device__ __forceinline__ uint32_t half_of(const uint4& v, int b) { // b-th f16 of 8 packed halfs (b constant)
+    uint32_t w = (b >> 1) == 0 ? v.x : (b >> 1) == 1 ? v.y : (b >> 1) == 2 ? v.z : v.w;
+    return (b & 1) ? (w >> 16) : (w & 0xFFFFu);
+}
+
+// =====================================================================================================
+// Q8_0 GEMV / skinny GEMM (spec S3).  One wave = R rows x one 256-element segment; LPR = 64/R lanes share
+// a row, each lane streaming 16 B (half a 32-block) per load.  A workgroup = up to 8 waves = one
+// 2048-element super-segment; segment chains are combined in order through LDS.
+// =====================================================================================================
+template <int LPR, int MT>
+__global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
+                                                 const uint16_t* __restrict__ xd, float* __restrict__ out,
+                                                 int out_stride, int ntok) {
+    constexpr int R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    __shared__ float red[8][R * MT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    const int tok0 = blockIdx.z * MT;
+    const bool active = seg < nseg; // wave-uniform
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.0f;
+    if (active) {
+        int row = row0 + blockIdx.x * R + r;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+        uint4 wv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
+        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int tok = tok0 + m;
+            if (tok > ntok - 1) tok = ntok - 1;
+            const int8_t* xp = xq + (size_t)tok * w.K + seg * 256;
+            const uint4 dxv = *reinterpret_cast<const uint4*>(xd + (size_t)tok * nb + seg * 8);
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xp + (i * BPL + bil) * 32 + half * 16);
+                int isum = dot16(wv[i], xv);
+                isum += __shfl_xor(isum, R); // the other half of the same 32-block: exact integer add
+#pragma unroll
+                for (int j = 0; j < BPL; j++) {
+                    const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
+                    const int b = i * BPL + j;
+                    const float sc = h2f(half_of(dwv, b)) * h2f(half_of(dxv, b));
+                    acc[m] = q3_fmaf((float)isj, sc, acc[m]);
+                }
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
+        }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < R * MT) {
+        const int m = t / R, rr = t % R;
+        int nsg = nseg - sseg * 8;
+        if (nsg > 8) nsg = 8;
+        float S = red[0][t];
+        for (int s = 1; s < nsg; s++) S = S + red[s][t];
+        const int orow = blockIdx.x * R + rr, tok = tok0 + m;
+        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+    }
+}
+
+template <int LPR, int MT>
+static void gemv_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
+                        float* out, int out_stride, int ntok) {
+    constexpr int R = 64 / LPR;
+    const int nseg = w.K >> 8, nsseg = (nseg + 7) / 8;
+    dim3 grid((nrows + R - 1) / R, nsseg, (ntok + MT - 1) / MT);
+    const int nw = nseg < 8 ? nseg : 8;
+    hipLaunchKernelGGL((k_gemv_q8<LPR, MT>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+}
+template <int LPR>
+static void gemv_launch_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
+                           float* out, int out_stride, int ntok) {
+    if (ntok == 1) gemv_launch<LPR, 1>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else if (ntok == 2) gemv_launch<LPR, 2>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else if (ntok <= 4) gemv_launch<LPR, 4>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else gemv_launch<LPR, 8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+}
+void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
+                    float* out, int out_stride, int ntok, int lpr_hint) {
+    const int nsseg = ((w.K >> 8) + 7) / 8;
+    int lpr = lpr_hint;
+    if (!lpr) { // enough workgroups to cover 256 CUs twice, else narrower row groups
+        if ((long)(nrows / 32) * nsseg >= 512) lpr = 2;
+        else if ((long)(nrows / 16) * nsseg >= 256) lpr = 4;
+        else lpr = 8;
+    }
+    if (lpr == 2) gemv_launch_mt<2>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else if (lpr == 4) gemv_launch_mt<4>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else gemv_launch_mt<8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+}
+
+// =====================================================================================================
+// residual + RMSNorm + int8 activation quantisation (spec S4, S2, S9).  One wave per token: lane l owns
+// elements 256c+4l..+3 of every 256-chunk; fma chain in index order; xor butterfly.
+// =====================================================================================================
+__global__ void __launch_bounds__(64) k_rmsnorm_quant(NormArgs a) {
+    const int tok = blockIdx.x, lane = threadIdx.x;
+    const int nch = a.d >> 8;
+    const float* hin = a.h_in;
+    if (a.idx) hin += (size_t)a.idx[(size_t)tok * a.idx_stride] * a.h_stride;
+    else hin += (size_t)tok * a.h_stride;
+    float4 x[8];
+    float p = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (c < nch) {
+            float4 v = *reinterpret_cast<const float4*>(hin + 256 * c + 4 * lane);
+            if (a.nparts > 0) { // y = S0; y += S1; ...; h = h + y
+                const float* pp = a.parts + (size_t)tok * a.parts_stride + 256 * c + 4 * lane;
+                float4 y = *reinterpret_cast<const float4*>(pp);
+                for (int s = 1; s < a.nparts; s++) {
+                    const float4 z = *reinterpret_cast<const float4*>(pp + (size_t)s * gridDim.x * a.parts_stride);
+                    y.x = y.x + z.x; y.y = y.y + z.y; y.z = y.z + z.z; y.w = y.w + z.w;
+                }
+                v.x = v.x + y.x; v.y = v.y + y.y; v.z = v.z + y.z; v.w = v.w + y.w;
+            }
+            if (a.h_out) *reinterpret_cast<float4*>(a.h_out + (size_t)tok * a.d + 256 * c + 4 * lane) = v;
+            x[c] = v;
+            p = q3_fmaf(v.x, v.x, p); p = q3_fmaf(v.y, v.y, p); p = q3_fmaf(v.z, v.z, p); p = q3_fmaf(v.w, v.w, p);
+        }
+    }
+    const float ss = wave_sum_bfly(p);
+    const float mean = ss / (float)a.d;
+    const float scale = 1.0f / q3_sqrtf(mean + a.eps);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (c < nch) {
+            const float4 g = *reinterpret_cast<const float4*>(a.g + 256 * c + 4 * lane);
+            float4 y;
+            y.x = (x[c].x * scale) * g.x; y.y = (x[c].y * scale) * g.y;
+            y.z = (x[c].z * scale) * g.z; y.w = (x[c].w * scale) * g.w;
+            if (a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * a.d + 256 * c + 4 * lane) = y;
+            float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
+            amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+            const float dd = amax / 127.0f;
+            const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+            const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
+            const uint32_t pk = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3v & 0xFF) << 24);
+            *reinterpret_cast<uint32_t*>(a.xq + (size_t)tok * a.d + 256 * c + 4 * lane) = pk;
+            if ((lane & 7) == 0) a.xd[(size_t)tok * (a.d >> 5) + 8 * c + (lane >> 3)] = f2h(dd);
+        }
+    }
+}
+void launch_rmsnorm_quant(hipStream_t st, const NormArgs& a, int ntok) {
+    hipLaunchKernelGGL(k_rmsnorm_quant, dim3(ntok), dim3(64), 0, st, a);
+}
+
+// =====================================================================================================
+// per-head RMSNorm + NeoX (M-)RoPE + KV append (spec S4', S5, S6).  One wave per (token, head vector);
+// lane l owns the rotation pair (x[l], x[l+64]).
+// =====================================================================================================
+__global__ void __launch_bounds__(64) k_qk_rope_append(const float* __restrict__ qkv, int qkv_stride, int n_head, int n_kv,
+                                                       const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w,
+                                                       float eps, const float* __restrict__ rope_cos,
+                                                       const float* __restrict__ rope_sin, int n_ctx,
+                                                       const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv,
+                                                       int layer, float* __restrict__ qrot) {
+    const int hv = blockIdx.x, tok = blockIdx.y, lane = threadIdx.x;
+    const float* vec = qkv + (size_t)tok * qkv_stride + (size_t)hv * 128;
+    float x1 = vec[lane], x2 = vec[lane + 64];
+    const int seq = tm.seq[tok], slot = tm.slot[tok];
+    const int page = kv.page_table[(size_t)seq * kv.max_pages + (slot >> 6)];
+    const int ps = slot & 63;
+    if (hv < n_head + n_kv) {
+        const float* w = hv < n_head ? q_norm_w : k_norm_w;
+        float p = x1 * x1;
+        p = q3_fmaf(x2, x2, p);
+        const float ss = wave_sum_bfly(p);
+        const float mean = ss / 128.0f;
+        const float scale = 1.0f / q3_sqrtf(mean + eps);
+        const float y1 = (x1 * scale) * w[lane], y2 = (x2 * scale) * w[lane + 64];
+        int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
+        int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+        if (pp < 0) pp = 0;
+        if (pp > n_ctx - 1) pp = n_ctx - 1;
+        float o1, o2;
+        q3_rope_pair(y1, y2, rope_cos[(size_t)pp * 64 + lane], rope_sin[(size_t)pp * 64 + lane], &o1, &o2);
+        if (hv < n_head) {
+            float* dst = qrot + ((size_t)tok * n_head + hv) * 128;
+            dst[lane] = o1; dst[lane + 64] = o2;
+        } else {
+            const int kh = hv - n_head;
+            uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + (size_t)layer * kv.layer_stride() + (size_t)kh * 8192;
+            // element d -> [d/8][pos][d%8]
+            Kb[((lane >> 3) * 64 + ps) * 8 + (lane & 7)] = f2h(o1);
+            Kb[(((lane + 64) >> 3) * 64 + ps) * 8 + (lane & 7)] = f2h(o2);
+        }
+    } else {
+        const int vh = hv - n_head - n_kv;
+        uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + (size_t)layer * kv.layer_stride() + (size_t)vh * 8192;
+        Vb[ps * 128 + lane] = f2h(x1);
+        Vb[ps * 128 + lane + 64] = f2h(x2);
+    }
+}
+void launch_qk_rope_append(hipStream_t st, const float* qkv, int qkv_stride, const float*, int n_head, int n_kv,
+                           const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos,
+                           const float* rope_sin, int n_ctx, const int32_t* mrope_sec, const TokMeta& tm,
+                           const KvCache& kv, int layer, float* qrot, int ntok) {
+    hipLaunchKernelGGL(k_qk_rope_append, dim3(n_head + 2 * n_kv, ntok), dim3(64), 0, st, qkv, qkv_stride, n_head, n_kv,
+                       q_norm_w, k_norm_w, eps, rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, qrot);
+}
+
+// =====================================================================================================
+// causal GQA decode attention over the paged f16 cache (spec S7).  Workgroup = 4 waves per (head, token):
+// wave w scores positions c0+64w+lane of each 256-chunk (K stored [d/8][pos][8] so a wave load is 1 KiB
+// contiguous), then accumulates PV chains r = 4w + lane/16 over positions j = r (mod 16).
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qrot, int n_head, int n_kv, TokMeta tm,
+                                                   KvCache kv, int layer, float* __restrict__ att,
+                                                   int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+    __shared__ float q_s[128];
+    __shared__ float p_s[256];
+    __shared__ float red_s[4][128];
+    __shared__ float wmax_s[4];
+    const int h = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = tm.seq[tok], n = tm.slot[tok] + 1;
+    const int kvh = h / (n_head / n_kv);
+    const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
+    const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
+    if (tid < 128) q_s[tid] = qrot[((size_t)tok * n_head + h) * 128 + tid];
+    __syncthreads();
+    const float scale = 0.08838834764831845f;
+    const int jj = lane >> 4, dc = lane & 15;
+    float M = 0.0f, L = 0.0f, O[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) O[i] = 0.0f;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int jbase = c0 + wave * 64;
+        const bool valid = (jbase + lane) < n;
+        float s = -INFINITY;
+        if (jbase < n) {
+            const int page = pt[jbase >> 6];
+            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+            float acc = 0.0f;
+#pragma unroll
+            for (int d8 = 0; d8 < 16; d8++) {
+                const uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+                const float4 qa = *reinterpret_cast<const float4*>(&q_s[8 * d8]);
+                const float4 qb = *reinterpret_cast<const float4*>(&q_s[8 * d8 + 4]);
+                acc = q3_fmaf(qa.x, h2f(kk.x & 0xFFFFu), acc); acc = q3_fmaf(qa.y, h2f(kk.x >> 16), acc);
+                acc = q3_fmaf(qa.z, h2f(kk.y & 0xFFFFu), acc); acc = q3_fmaf(qa.w, h2f(kk.y >> 16), acc);
+                acc = q3_fmaf(qb.x, h2f(kk.z & 0xFFFFu), acc); acc = q3_fmaf(qb.y, h2f(kk.z >> 16), acc);
+                acc = q3_fmaf(qb.z, h2f(kk.w & 0xFFFFu), acc); acc = q3_fmaf(qb.w, h2f(kk.w >> 16), acc);
+            }
+            if (valid) s = acc * scale;
+        }
+        const float wm = wave_max_bfly(s);
+        if (lane == 0) wmax_s[wave] = wm;
+        __syncthreads();
+        const float mc = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+        const float p = valid ? q3_expf(s - mc) : 0.0f;
+        p_s[wave * 64 + lane] = p;
+        __syncthreads();
+        // PV: 16 chains; this wave owns chains 4*wave+jj
+        float S[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[i] = 0.0f;
+        const int cn = (n - c0) < 256 ? (n - c0) : 256;
+#pragma unroll 4
+        for (int u = 0; u < 16; u++) {
+            if (16 * u < cn) {
+                const int jl = 16 * u + 4 * wave + jj;
+                const int jg = c0 + jl;
+                const float pj = p_s[jl];
+                uint4 vv = make_uint4(0, 0, 0, 0);
+                if (jg < n) {
+                    const int page = pt[jg >> 6];
+                    vv = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
+                }
+                S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
+                S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
+                S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
+                S[6] = q3_fmaf(pj, h2f(vv.w & 0xFFFFu), S[6]); S[7] = q3_fmaf(pj, h2f(vv.w >> 16), S[7]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float a = S[i] + __shfl_xor(S[i], 16);   // (S0+S1) | (S2+S3)
+            const float T = a + __shfl_xor(a, 32);          // (S0+S1)+(S2+S3)
+            if (jj == 0) red_s[wave][dc * 8 + i] = T;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float a = p_s[lane];                            // spec: a = 0 + p0 (== p0), then + p1, p2, p3
+            a = a + p_s[lane + 64]; a = a + p_s[lane + 128]; a = a + p_s[lane + 192];
+            const float lc = wave_sum_bfly(a);
+            float oc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) oc[i] = (red_s[0][dc * 8 + i] + red_s[1][dc * 8 + i]) + (red_s[2][dc * 8 + i] + red_s[3][dc * 8 + i]);
+            if (c0 == 0) {
+                M = mc; L = lc;
+#pragma unroll
+                for (int i = 0; i < 8; i++) O[i] = oc[i];
+            } else {
+                const float mn = fmaxf(M, mc);
+                const float ea = q3_expf(M - mn), eb = q3_expf(mc - mn);
+                const float t = lc * eb;
+                L = q3_fmaf(L, ea, t);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const float u2 = oc[i] * eb; O[i] = q3_fmaf(O[i], ea, u2); }
+                M = mn;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float y[8];
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { y[i] = O[i] / L; amax = fmaxf(amax, q3_fabsf(y[i])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        const float dd = amax / 127.0f;
+        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+        if (jj == 0) {
+            const size_t o = ((size_t)tok * n_head + h) * 128 + dc * 8;
+            if (att) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) att[o + i] = y[i];
+            }
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lo |= (uint32_t)((int)q3_rintf(y[i] * id) & 0xFF) << (8 * i);
+                hi |= (uint32_t)((int)q3_rintf(y[i + 4] * id) & 0xFF) << (8 * i);
+            }
+            *reinterpret_cast<uint2*>(aq + o) = make_uint2(lo, hi);
+            if ((dc & 3) == 0) ad[o >> 5] = f2h(dd);
+        }
+    }
+}
+void launch_attention(hipStream_t st, const float* qrot, int n_head, int n_kv, const TokMeta& tm, const KvCache& kv,
+                      int layer, float* att, int8_t* aq, uint16_t* ad, int ntok) {
+    hipLaunchKernelGGL(k_attention, dim3(n_head, ntok), dim3(256), 0, st, qrot, n_head, n_kv, tm, kv, layer, att, aq, ad);
+}
+
+// =====================================================================================================
+// SwiGLU + quantise (spec S8, S2): thread handles 4 consecutive elements; 8 threads = one 32-block.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_swiglu_quant(const float* __restrict__ gu, int ff, int8_t* __restrict__ aq,
+                                                      uint16_t* __restrict__ ad) {
+    const int tok = blockIdx.y;
+    const int e = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (e >= ff) return; // ff % 32 == 0 and 8-lane groups are aligned, so whole groups exit together
+    const float4 g = *reinterpret_cast<const float4*>(gu + (size_t)tok * 2 * ff + e);
+    const float4 u = *reinterpret_cast<const float4*>(gu + (size_t)tok * 2 * ff + ff + e);
+    float4 y;
+    y.x = q3_swiglu(g.x, u.x); y.y = q3_swiglu(g.y, u.y); y.z = q3_swiglu(g.z, u.z); y.w = q3_swiglu(g.w, u.w);
+    float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    const float dd = amax / 127.0f;
+    const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+    const uint32_t pk = (uint32_t)((int)q3_rintf(y.x * id) & 0xFF) | ((uint32_t)((int)q3_rintf(y.y * id) & 0xFF) << 8) |
+                        ((uint32_t)((int)q3_rintf(y.z * id) & 0xFF) << 16) | ((uint32_t)((int)q3_rintf(y.w * id) & 0xFF) << 24);
+    *reinterpret_cast<uint32_t*>(aq + (size_t)tok * ff + e) = pk;
+    if ((threadIdx.x & 7) == 0) ad[(size_t)tok * (ff >> 5) + (e >> 5)] = f2h(dd);
+}
+void launch_swiglu_quant(hipStream_t st, const float* gu, int ff, int8_t* aq, uint16_t* ad, int ntok) {
+    hipLaunchKernelGGL(k_swiglu_quant, dim3((ff / 4 + 255) / 256, ntok), dim3(256), 0, st, gu, ff, aq, ad);
+}
+
+// =====================================================================================================
+// first-max argmax (llama/mod.rs:690-701)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_argmax(const float* __restrict__ logits, int stride, int start, int end,
+                                                const int32_t* __restrict__ mask_per_tok, int32_t* __restrict__ out,
+                                                int out_stride, int add) {
+    __shared__ float bv[256];
+    __shared__ int bi[256];
+    const int tok = blockIdx.x, t = threadIdx.x;
+    const int mask_idx = mask_per_tok ? mask_per_tok[tok] : -1;
+    const float* lg = logits + (size_t)tok * stride;
+    float mv = -INFINITY;
+    int mi = start;
+    for (int i = start + t; i < end; i += 256) {
+        const float v = (i == mask_idx) ? -INFINITY : lg[i];
+        if (v > mv) { mv = v; mi = i; } // ascending i within a thread: first max kept
+    }
+    bv[t] = mv; bi[t] = mi;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) {
+        if (t < s) {
+            const float v2 = bv[t + s]; const int i2 = bi[t + s];
+            if (v2 > bv[t] || (v2 == bv[t] && i2 < bi[t])) { bv[t] = v2; bi[t] = i2; }
+        }
+        __syncthreads();
+    }
+    if (t == 0) out[(size_t)tok * out_stride] = bi[0] + add;
+}
+void launch_argmax(hipStream_t st, const float* logits, int stride, int start, int end, const int32_t* mask_per_tok,
+                   int32_t* out, int out_stride, int add, int ntok) {
+    hipLaunchKernelGGL(k_argmax, dim3(ntok), dim3(256), 0, st, logits, stride, start, end, mask_per_tok, out, out_stride, add);
+}
+
+// =====================================================================================================
+// 2048 -> 1024 projection with the reference's exact order (assets_manager.rs:383-399): one thread per
+// output, bias first, ascending i, separate mul and add.  Wt is the transposed weight [n_in][n_out] so
+// that a wave reads 256 contiguous bytes per step.
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_project(const float* __restrict__ x, int x_stride, const float* __restrict__ Wt,
+                                                 const float* __restrict__ b, int n_in, int n_out,
+                                                 float* __restrict__ out, int out_stride) {
+    extern __shared__ float xs[];
+    const int tok = blockIdx.y, o = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < n_in; i += 256) xs[i] = x[(size_t)tok * x_stride + i];
+    __syncthreads();
+    if (o >= n_out) return;
+    float sum = b[o];
+#pragma unroll 8
+    for (int i = 0; i < n_in; i++) { const float t = xs[i] * Wt[(size_t)i * n_out + o]; sum = sum + t; }
+    out[(size_t)tok * out_stride + o] = sum;
+}
+void launch_project(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
+                    float* out, int out_stride, int ntok) {
+    hipLaunchKernelGGL(k_project, dim3((n_out + 255) / 256, ntok), dim3(256), n_in * sizeof(float), st, x, x_stride, Wt, b,
+                       n_in, n_out, out, out_stride);
+}
+template <int CT>
+__global__ void __launch_bounds__(256) k_project_table(const float* __restrict__ table, int64_t rows,
+                                                       const float* __restrict__ Wt, const float* __restrict__ b,
+                                                       int n_in, int n_out, float* __restrict__ out) {
+    extern __shared__ float xs[]; // [CT][n_in]
+    const int64_t r0 = (int64_t)blockIdx.y * CT;
+    const int o = blockIdx.x * 256 + threadIdx.x;
+    for (int i = threadIdx.x; i < CT * n_in; i += 256) {
+        const int64_t r = r0 + i / n_in;
+        xs[i] = r < rows ? table[(size_t)r * n_in + (i % n_in)] : 0.0f;
+    }
+    __syncthreads();
+    if (o >= n_out) return;
+    float sum[CT];
+#pragma unroll
+    for (int c = 0; c < CT; c++) sum[c] = b[o];
+    for (int i = 0; i < n_in; i++) {
+        const float wv = Wt[(size_t)i * n_out + o];
+#pragma unroll
+        for (int c = 0; c < CT; c++) { const float t = xs[c * n_in + i] * wv; sum[c] = sum[c] + t; }
+    }
+#pragma unroll
+    for (int c = 0; c < CT; c++) if (r0 + c < rows) out[(size_t)(r0 + c) * n_out + o] = sum[c];
+}
+void launch_project_table(hipStream_t st, const float* table, int64_t rows, const float* Wt, const float* b, int n_in,
+                          int n_out, float* out) {
+    constexpr int CT = 4;
+    hipLaunchKernelGGL((k_project_table<CT>), dim3((n_out + 255) / 256, (unsigned)((rows + CT - 1) / CT)), dim3(256),
+                       CT * n_in * sizeof(float), st, table, rows, Wt, b, n_in, n_out, out);
+}
+
+// =====================================================================================================
+// feedback embedding (engine.rs:622-631)
+// =====================================================================================================
+__global__ void __launch_bounds__(256) k_feedback(const float* const* __restrict__ tables, const int64_t* __restrict__ table_rows,
+                                                  const int32_t* __restrict__ codes, int codes_stride,
+                                                  const float* __restrict__ tts_pad, float* __restrict__ out) {
+    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        int c = codes[(size_t)tok * codes_stride + q];
+        if (c < 0) c = 0; // assets_manager.rs:422
+        const float v = ((int64_t)c < table_rows[q]) ? tables[q][(size_t)c * 2048 + i] : 0.0f; // OOB -> zeros (:436)
+        acc = acc + v;
+    }
+    acc = acc + tts_pad[i];
+    out[(size_t)tok * 2048 + i] = acc;
+}
+void launch_feedback(hipStream_t st, const float* const* tables, const int64_t* table_rows, const int32_t* codes,
+                     int codes_stride, const float* tts_pad, float* out, int ntok) {
+    hipLaunchKernelGGL(k_feedback, dim3(8, ntok), dim3(256), 0, st, tables, table_rows, codes, codes_stride, tts_pad, out);
+}
+
+// row gather: dst[tok][:] = table[max(idx,0)][:]  (pre-projected codec rows -> predictor input)
+__global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ table, int64_t rows, const int32_t* __restrict__ idx,
+                                                     int idx_stride, int row_len, float* __restrict__ dst) {
+    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_len) return;
+    int c = idx[(size_t)tok * idx_stride];
+    if (c < 0) c = 0;
+    dst[(size_t)tok * row_len + i] = ((int64_t)c < rows) ? table[(size_t)c * row_len + i] : 0.0f;
+}
+void launch_gather_rows(hipStream_t st, const float* table, int64_t rows, const int32_t* idx, int idx_stride, int row_len,
+                        float* dst, int ntok) {
+    hipLaunchKernelGGL(k_gather_rows, dim3((row_len + 255) / 256, ntok), dim3(256), 0, st, table, rows, idx, idx_stride, row_len, dst);
+}
+
+// end-of-frame bookkeeping for each sequence (engine.rs:558-562 EOS test, :613-620 code hand-off, :641 cur_pos += 1)
+__global__ void k_advance(AdvanceArgs a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    if (a.finished[b] || a.n_frames[b] >= a.max_frames[b]) return; // idle / done: slot stays put (rewrites one slot)
+    const int c0 = a.cur_codes[b * 16];
+    if (c0 == Q3_CODEC_EOS || c0 == Q3_TEXT_EOS) { a.finished[b] = 1; return; }
+    int32_t* dst = a.hist + (size_t)b * a.hist_stride + (size_t)a.n_frames[b] * 16;
+    for (int q = 0; q < 16; q++) dst[q] = a.cur_codes[b * 16 + q];
+    a.n_frames[b] = a.n_frames[b] + 1;
+    a.t_slot[b] = a.t_slot[b] + 1;
+    a.t_pos[b * 4 + 0] += 1; a.t_pos[b * 4 + 1] += 1; a.t_pos[b * 4 + 2] += 1; // engine.rs:306-314: stream 3 stays 0
+}
+void launch_advance(hipStream_t st, const AdvanceArgs& a) {
+    hipLaunchKernelGGL(k_advance, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+}
+
+__global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n) {
+    hipLaunchKernelGGL(k_copy_f32, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n);
+}
+
+} // namespace q3

@@ -1,0 +1,216 @@
+// transformer.cpp -- see transformer.h.  (compiled by hipcc as HIP: contains the load-time repack kernel)
+#include "transformer.h"
+#include <cmath>
+
+namespace q3 {
+
+// ---- load-time repack: GGUF Q8_0 rows ([n][K/32]{f16 d; i8 qs[32]}) -> Q8Mat tiles (kernels.h) ----
+__global__ void k_repack_q8(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs,
+                            uint16_t* __restrict__ sc) {
+    const int nb = K >> 5, nseg = K >> 8;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * nb) return;
+    const int r = (int)(id / nb), b = (int)(id % nb);
+    const uint8_t* src = raw + id * 34;
+    const int row = row_off + r, rg = row >> 5, r32 = row & 31;
+    uint16_t d;
+    memcpy(&d, src, 2);
+    sc[(((size_t)rg * nseg + (b >> 3)) * 32 + r32) * 8 + (b & 7)] = d;
+    uint8_t* dst = qs + ((size_t)rg * nb + b) * 1024 + r32 * 16;
+    for (int i = 0; i < 16; i++) { dst[i] = src[2 + i]; dst[512 + i] = src[18 + i]; }
+}
+
+Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& storage) {
+    Q3_CHECK(k % 256 == 0 && n > 0, "bad Q8_0 matrix shape");
+    Q8Mat m;
+    m.N = n; m.Npad = (n + 31) & ~31; m.K = k;
+    const size_t qs_bytes = (size_t)m.Npad * k, sc_bytes = (size_t)m.Npad * (k / 32) * 2;
+    storage.alloc(qs_bytes + sc_bytes);
+    storage.zero();
+    m.qs = storage.p;
+    m.sc = reinterpret_cast<const uint16_t*>(storage.p + qs_bytes);
+    const size_t raw_bytes = (size_t)n * (k / 32) * 34;
+    DevBuf<uint8_t> raw(raw_bytes);
+    raw.upload((const uint8_t*)raw_q8_0, raw_bytes);
+    const size_t nblk = (size_t)n * (k / 32);
+    hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, n, k, 0, storage.p,
+                       reinterpret_cast<uint16_t*>(storage.p + qs_bytes));
+    Q3_HIP(hipDeviceSynchronize());
+    return m;
+}
+
+Q8Mat Transformer::make_mat(int N, int K) {
+    Q3_CHECK(K % 256 == 0, "K must be a multiple of 256");
+    Q8Mat m;
+    m.N = N; m.Npad = (N + 31) & ~31; m.K = K;
+    const size_t qs_bytes = (size_t)m.Npad * K, sc_bytes = (size_t)m.Npad * (K / 32) * 2;
+    blobs_.emplace_back(qs_bytes + sc_bytes);
+    blobs_.back().zero();
+    m.qs = blobs_.back().p;
+    m.sc = reinterpret_cast<const uint16_t*>(blobs_.back().p + qs_bytes);
+    return m;
+}
+
+void Transformer::load_into(const Gguf& g, const std::string& name, Q8Mat& dst, int row_off, int K_expect) {
+    const GgufTensor& t = g.need(name);
+    if (t.type != Q3_T_Q8_0)
+        throw Error("tensor " + name + ": type " + std::to_string(t.type) + " not supported by the HIP path yet (Q8_0 only)");
+    Q3_CHECK(t.ne[0] == K_expect, "unexpected K for " + name);
+    Q3_CHECK(row_off % 32 == 0 && row_off + t.ne[1] <= dst.Npad, "bad row offset for " + name);
+    DevBuf<uint8_t> raw(t.nbytes);
+    raw.upload(t.data, t.nbytes);
+    const size_t nblk = (size_t)t.ne[1] * (t.ne[0] / 32);
+    hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0],
+                       row_off, const_cast<uint8_t*>(dst.qs), const_cast<uint16_t*>(dst.sc));
+    Q3_HIP(hipDeviceSynchronize());
+}
+
+float* Transformer::load_f32(const Gguf& g, const std::string& name, int64_t n_expect) {
+    const GgufTensor& t = g.need(name);
+    Q3_CHECK(t.type == Q3_T_F32 && t.ne[0] * t.rows() == n_expect, "bad f32 tensor " + name);
+    blobs_.emplace_back((size_t)n_expect * 4);
+    blobs_.back().upload(t.data, (size_t)n_expect * 4);
+    return reinterpret_cast<float*>(blobs_.back().p);
+}
+
+Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ctx_(n_ctx), max_tok_(max_tok) {
+    Gguf g(path);
+    hp_.arch = g.kv_str("general.architecture", "qwen3");
+    auto K = [&](const char* s) { return hp_.arch + "." + s; };
+    hp_.n_embd = (int)g.kv_int(K("embedding_length"), 0);
+    hp_.n_layer = (int)g.kv_int(K("block_count"), 0);
+    hp_.n_head = (int)g.kv_int(K("attention.head_count"), 0);
+    hp_.n_kv = (int)g.kv_int(K("attention.head_count_kv"), hp_.n_head);
+    const int head_dim = (int)g.kv_int(K("attention.key_length"), hp_.n_head ? hp_.n_embd / hp_.n_head : 0);
+    hp_.n_ff = (int)g.kv_int(K("feed_forward_length"), 0);
+    hp_.eps = (float)g.kv_float(K("attention.layer_norm_rms_epsilon"), 1e-6);
+    hp_.rope_base = (float)g.kv_float(K("rope.freq_base"), 1e6);
+    if (auto* s = g.kv(K("rope.dimension_sections")))
+        for (size_t i = 0; i < s->arr_i.size() && i < 4; i++) hp_.mrope_sec[i] = (int32_t)s->arr_i[i];
+    Q3_CHECK(hp_.n_embd > 0 && hp_.n_layer > 0 && hp_.n_head > 0 && head_dim == Q3_HEAD_DIM, "unsupported hparams");
+    Q3_CHECK(hp_.n_embd % 256 == 0 && hp_.n_embd <= 2048 && hp_.n_ff % 256 == 0 && hp_.n_head % hp_.n_kv == 0, "unsupported dims");
+    Q3_CHECK(hp_.n_head * 128 <= 2048, "n_head*128 must be <= 2048 (single super-segment o-proj)");
+    const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    layers_.resize(hp_.n_layer);
+    for (int l = 0; l < hp_.n_layer; l++) {
+        Layer& L = layers_[l];
+        const std::string p = "blk." + std::to_string(l) + ".";
+        L.wqkv = make_mat(dq + 2 * dkv, d);
+        load_into(g, p + "attn_q.weight", L.wqkv, 0, d);
+        load_into(g, p + "attn_k.weight", L.wqkv, dq, d);
+        load_into(g, p + "attn_v.weight", L.wqkv, dq + dkv, d);
+        L.wo = make_mat(d, dq);
+        load_into(g, p + "attn_output.weight", L.wo, 0, dq);
+        L.wgu = make_mat(2 * ff, d);
+        load_into(g, p + "ffn_gate.weight", L.wgu, 0, d);
+        load_into(g, p + "ffn_up.weight", L.wgu, ff, d);
+        L.wdown = make_mat(d, ff);
+        load_into(g, p + "ffn_down.weight", L.wdown, 0, ff);
+        L.attn_norm = load_f32(g, p + "attn_norm.weight", d);
+        L.q_norm = load_f32(g, p + "attn_q_norm.weight", 128);
+        L.k_norm = load_f32(g, p + "attn_k_norm.weight", 128);
+        L.ffn_norm = load_f32(g, p + "ffn_norm.weight", d);
+        if (l == 0) layer_weight_bytes_ = L.wqkv.bytes() + L.wo.bytes() + L.wgu.bytes() + L.wdown.bytes();
+        weight_bytes_ += L.wqkv.bytes() + L.wo.bytes() + L.wgu.bytes() + L.wdown.bytes();
+    }
+    output_norm_ = load_f32(g, "output_norm.weight", d);
+    const GgufTensor& ot = g.need("output.weight");
+    hp_.n_vocab = (int)ot.ne[1];
+    output_ = make_mat(hp_.n_vocab, d);
+    load_into(g, "output.weight", output_, 0, d);
+    // RoPE tables: same double-precision expressions as the oracle (spec S5)
+    std::vector<float> c((size_t)n_ctx * 64), s((size_t)n_ctx * 64);
+    for (int p = 0; p < n_ctx; p++)
+        for (int i = 0; i < 64; i++) {
+            const double inv = std::pow((double)hp_.rope_base, -(double)i / 64.0);
+            const double ang = (double)p * inv;
+            c[(size_t)p * 64 + i] = (float)std::cos(ang);
+            s[(size_t)p * 64 + i] = (float)std::sin(ang);
+        }
+    rope_cos_.alloc(c.size()); rope_cos_.upload(c.data(), c.size());
+    rope_sin_.alloc(s.size()); rope_sin_.upload(s.data(), s.size());
+    d_mrope_.alloc(4); d_mrope_.upload(hp_.mrope_sec, 4);
+    nparts_d_ = ((ff >> 8) + 7) / 8;
+    const size_t T = (size_t)max_tok;
+    h_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
+    qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
+    const size_t mx = (size_t)(d > dq ? d : dq);
+    xq_.alloc(T * mx); xd_.alloc(T * mx / 32); aq_.alloc(T * dq); ad_.alloc(T * dq / 32); fq_.alloc(T * ff); fd_.alloc(T * ff / 32);
+}
+
+void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
+                       int out_stride, int ntok) {
+    if (timer) timer->begin(st);
+    launch_gemv_q8(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    if (timer) timer->end(st, (double)nrows * ((double)w.K + (double)(w.K / 32) * 2.0));
+}
+
+void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
+    Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
+    const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    for (int l = 0; l < hp_.n_layer; l++) {
+        const Layer& L = layers_[l];
+        NormArgs a{};
+        if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx = in.idx; a.idx_stride = in.idx_stride; a.nparts = 0; }
+        else { a.h_in = h_.p; a.h_stride = d; a.parts = parts_d_.p; a.nparts = nparts_d_; a.parts_stride = d; }
+        a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p;
+        launch_rmsnorm_quant(st, a, ntok);
+        gemv(st, L.wqkv, 0, dq + 2 * dkv, xq_.p, xd_.p, qkv_.p, dq + 2 * dkv, ntok);
+        launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
+                              rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
+        launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
+        gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
+        NormArgs b{};
+        b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.h_out = h_.p;
+        b.g = L.ffn_norm; b.eps = hp_.eps; b.d = d; b.xq = xq_.p; b.xd = xd_.p;
+        launch_rmsnorm_quant(st, b, ntok);
+        gemv(st, L.wgu, 0, 2 * ff, xq_.p, xd_.p, gu_.p, 2 * ff, ntok);
+        launch_swiglu_quant(st, gu_.p, ff, fq_.p, fd_.p, ntok);
+        gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
+    }
+    NormArgs f{};
+    f.h_in = h_.p; f.h_stride = d; f.parts = parts_d_.p; f.nparts = nparts_d_; f.parts_stride = d; f.h_out = nullptr;
+    f.g = output_norm_; f.eps = hp_.eps; f.d = d; f.xq = xq_.p; f.xd = xd_.p; f.xn_out = hidden_out;
+    launch_rmsnorm_quant(st, f, ntok);
+}
+
+void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride) {
+    const int d = hp_.n_embd;
+    Q3_CHECK(row0 % 32 == 0 && row0 + nrows <= output_.Npad, "head row range");
+    gemv(st, output_, row0, nrows, xq_.p + (size_t)tok0 * d, xd_.p + (size_t)tok0 * (d / 32), logits, logits_stride, tok_count);
+}
+
+// ------------------------------------------------------------------------------------------------
+KvPool::KvPool(int n_layer, int n_kv, int n_pages, int n_seq, int max_pages_per_seq)
+    : n_layer_(n_layer), n_kv_(n_kv), n_pages_(n_pages), n_seq_(n_seq), max_pages_(max_pages_per_seq) {
+    const size_t per_page = (size_t)n_layer * n_kv * 8192;
+    k_.alloc(per_page * n_pages); v_.alloc(per_page * n_pages);
+    k_.zero(); v_.zero();
+    table_.assign((size_t)n_seq * max_pages_per_seq, 0);
+    d_table_.alloc(table_.size());
+    d_table_.upload(table_.data(), table_.size());
+    for (int p = n_pages - 1; p >= 0; p--) free_.push_back(p);
+    used_pages_.assign(n_seq, 0);
+}
+KvCache KvPool::view() const {
+    KvCache c;
+    c.k = k_.p; c.v = v_.p; c.page_table = d_table_.p; c.max_pages = max_pages_; c.n_layer = n_layer_; c.n_kv = n_kv_;
+    return c;
+}
+int KvPool::alloc_page() { Q3_CHECK(!free_.empty(), "KV pool exhausted"); int p = free_.back(); free_.pop_back(); return p; }
+void KvPool::free_page(int p) { free_.push_back(p); }
+void KvPool::assign(int seq, int lp, int pp) {
+    table_[(size_t)seq * max_pages_ + lp] = pp;
+    Q3_HIP(hipMemcpy(d_table_.p + (size_t)seq * max_pages_ + lp, &pp, 4, hipMemcpyHostToDevice));
+}
+void KvPool::ensure(int seq, int n_positions) {
+    const int need = (n_positions + 63) / 64;
+    Q3_CHECK(need <= max_pages_, "sequence exceeds max pages");
+    while (used_pages_[seq] < need) { assign(seq, used_pages_[seq], alloc_page()); used_pages_[seq]++; }
+}
+void KvPool::release(int seq) {
+    for (int i = 0; i < used_pages_[seq]; i++) free_page(table_[(size_t)seq * max_pages_ + i]);
+    used_pages_[seq] = 0;
+}
+
+} // namespace q3

@@ -1,0 +1,91 @@
+// transformer.h -- device-resident Qwen3-style decoder (talker / code predictor) driven from embeddings.
+// Replaces the llama.cpp objects behind LlamaModel / LlamaContext (/root/reference/src/models/llama/mod.rs:326-513).
+#pragma once
+#include "q3_common.h"
+#include "gguf.h"
+#include "kernels.h"
+#include <memory>
+
+namespace q3 {
+
+struct TfHparams {
+    std::string arch;
+    int n_embd = 0, n_layer = 0, n_head = 0, n_kv = 0, n_ff = 0, n_vocab = 0;
+    float eps = 1e-6f, rope_base = 1e6f;
+    int32_t mrope_sec[4] = {0, 0, 0, 0};
+};
+
+class Transformer {
+public:
+    Transformer(const std::string& gguf_path, int n_ctx, int max_tok);
+    const TfHparams& hp() const { return hp_; }
+    int n_ctx() const { return n_ctx_; }
+    int max_tok() const { return max_tok_; }
+    size_t weight_bytes() const { return weight_bytes_; }       // repacked matmul weights (algorithmic bytes/step)
+    size_t layer_weight_bytes() const { return layer_weight_bytes_; }
+    size_t head_bytes_per_row() const { return (size_t)hp_.n_embd + (size_t)(hp_.n_embd / 32) * 2; }
+
+    struct Input {
+        const float* x = nullptr; int x_stride = 0;   // [ntok][x_stride] embeddings ...
+        const int32_t* idx = nullptr; int idx_stride = 0; // ... or table rows: x + idx[tok*idx_stride]*x_stride
+    };
+    // Runs all layers for ntok tokens.  After return (on stream): xq_/xd_ hold the quantised final-norm hidden of
+    // every token; hidden_out (optional) gets the f32 final-norm hidden [ntok][n_embd].
+    void forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out);
+    // logits[tok_count][nrows] = output rows [row0,row0+nrows) . final hidden of tokens [tok0, tok0+tok_count)
+    void head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride);
+
+    LaunchTimer* timer = nullptr; // optional per-GEMV-launch event timing (instrumented bench leg)
+    // op-level access for parity tests
+    const Q8Mat& mat_qkv(int l) const { return layers_[l].wqkv; }
+    const Q8Mat& mat_out() const { return output_; }
+
+private:
+    struct Layer { Q8Mat wqkv, wo, wgu, wdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
+    void gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
+              int out_stride, int ntok);
+    Q8Mat make_mat(int N, int K);
+    void load_into(const Gguf& g, const std::string& name, Q8Mat& dst, int row_off, int K_expect);
+    float* load_f32(const Gguf& g, const std::string& name, int64_t n_expect);
+    TfHparams hp_;
+    int n_ctx_ = 0, max_tok_ = 0;
+    std::vector<Layer> layers_;
+    Q8Mat output_;
+    float* output_norm_ = nullptr;
+    std::vector<DevBuf<uint8_t>> blobs_;
+    size_t weight_bytes_ = 0, layer_weight_bytes_ = 0;
+    DevBuf<float> rope_cos_, rope_sin_;
+    DevBuf<int32_t> d_mrope_;
+    // activations
+    DevBuf<float> h_, parts_o_, parts_d_, qkv_, qrot_, gu_;
+    DevBuf<int8_t> xq_, aq_, fq_;
+    DevBuf<uint16_t> xd_, ad_, fd_;
+    int nparts_d_ = 1;
+};
+
+// standalone repack of host GGUF Q8_0 rows into a device Q8Mat (storage owns the memory); used by parity ops
+Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& storage);
+
+// simple paged KV pool (pages of 64 positions) -- "paged KV cache sized for 288 GB HBM3E"
+class KvPool {
+public:
+    KvPool(int n_layer, int n_kv, int n_pages, int n_seq, int max_pages_per_seq);
+    KvCache view() const;
+    // host-side page accounting
+    int alloc_page();
+    void free_page(int p);
+    void assign(int seq, int logical_page, int physical_page); // updates host + device table
+    void ensure(int seq, int n_positions);                      // make sure pages for [0,n_positions) exist
+    void release(int seq);
+    int pages_free() const { return (int)free_.size(); }
+    size_t bytes() const { return (k_.n + v_.n) * 2; }
+private:
+    int n_layer_, n_kv_, n_pages_, n_seq_, max_pages_;
+    DevBuf<uint16_t> k_, v_;
+    DevBuf<int32_t> d_table_;
+    std::vector<int32_t> table_;
+    std::vector<int> free_;
+    std::vector<int> used_pages_; // per seq count
+};
+
+} // namespace q3

@@ -1,0 +1,390 @@
+"""ctypes binding over the C ABI of libq3tts.so (include/q3tts.h).
+
+Python here is harness plumbing for tests / bench only; the product is the shared library.  There is no
+fallback: if the library is missing or no HIP device is visible, compute entry points raise.
+"""
+import ctypes as C
+import os
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+PKG_ROOT = os.path.dirname(os.path.dirname(_HERE))
+LIB_PATH = os.path.join(PKG_ROOT, "libq3tts.so")
+_lib = None
+
+
+class Q3Error(RuntimeError):
+    pass
+
+
+class SamplerConfig(C.Structure):  # engine.rs:13-45
+    _fields_ = [("temperature", C.c_float), ("top_k", C.c_int32), ("top_p", C.c_float), ("has_seed", C.c_int32),
+                ("seed", C.c_uint64)]
+
+
+class EngineParams(C.Structure):
+    _fields_ = [("model_dir", C.c_char_p), ("quant", C.c_char_p), ("device", C.c_int32), ("max_batch", C.c_int32),
+                ("max_prompt", C.c_int32), ("max_steps", C.c_int32), ("load_codec", C.c_int32), ("use_graph", C.c_int32)]
+
+
+class Request(C.Structure):
+    _fields_ = [("prompt", C.c_void_p), ("n_prompt", C.c_int32), ("sampler", SamplerConfig), ("max_steps", C.c_int32),
+                ("mask_eos", C.c_int32), ("codes_out", C.c_void_p), ("pcm_out", C.c_void_p), ("pcm_capacity", C.c_int64),
+                ("n_frames", C.c_int32), ("n_pcm", C.c_int64), ("prefill_ms", C.c_double), ("first_chunk_ms", C.c_double),
+                ("total_ms", C.c_double)]
+
+
+class Stats(C.Structure):
+    _fields_ = [("frame_loop_ms", C.c_double), ("frames", C.c_int64), ("prefill_ms", C.c_double), ("gemv_ms", C.c_double),
+                ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double), ("codec_ms", C.c_double), ("codec_calls", C.c_int64),
+                ("talker_weight_bytes", C.c_double), ("predictor_weight_bytes", C.c_double), ("kv_bytes_per_token", C.c_double)]
+
+
+DECODE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
+
+# every symbol include/q3tts.h declares (checked by tests/test_abi.py)
+SYMBOLS = [
+    "q3tts_last_error", "q3tts_version", "q3tts_device_count", "q3tts_sampler_config_default", "q3tts_engine_params_default",
+    "q3tts_engine_create", "q3tts_engine_destroy", "q3tts_generate_batch", "q3tts_engine_stats", "q3tts_engine_reset_stats",
+    "q3tts_engine_set_instrument", "q3tts_engine_bytes_per_step", "q3tts_assets_open", "q3tts_assets_close", "q3tts_engine_assets",
+    "q3tts_assets_codec_embedding", "q3tts_assets_text_embedding", "q3tts_assets_tts_pad", "q3tts_prompt_build_core",
+    "q3tts_prompt_build_clone", "q3tts_sampler_new", "q3tts_sampler_free", "q3tts_sampler_sample", "q3tts_chunker_new",
+    "q3tts_chunker_free", "q3tts_chunker_push", "q3tts_decoder_create", "q3tts_decoder_destroy", "q3tts_decoder_samples_per_frame",
+    "q3tts_decoder_reset", "q3tts_decoder_decode", "q3tts_mel_frames", "q3tts_mel", "q3tts_tf_open", "q3tts_tf_close",
+    "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
+    "q3tts_op_argmax", "q3tts_op_project",
+]
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise Q3Error("libq3tts.so not built (run qwen3-tts-rust_amd/build.sh); there is no CPU fallback")
+        L = C.CDLL(LIB_PATH)
+        L.q3tts_last_error.restype = C.c_char_p
+        L.q3tts_engine_create.argtypes = [C.POINTER(EngineParams), C.POINTER(C.c_void_p)]
+        L.q3tts_engine_destroy.argtypes = [C.c_void_p]
+        L.q3tts_generate_batch.argtypes = [C.c_void_p, C.POINTER(Request), C.c_int32, C.c_int32]
+        L.q3tts_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.q3tts_engine_reset_stats.argtypes = [C.c_void_p]
+        L.q3tts_engine_set_instrument.argtypes = [C.c_void_p, C.c_int32]
+        L.q3tts_engine_bytes_per_step.restype = C.c_double
+        L.q3tts_engine_bytes_per_step.argtypes = [C.c_void_p, C.c_int32, C.c_double]
+        L.q3tts_assets_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.q3tts_assets_close.argtypes = [C.c_void_p]
+        L.q3tts_engine_assets.restype = C.c_void_p
+        L.q3tts_engine_assets.argtypes = [C.c_void_p]
+        L.q3tts_assets_codec_embedding.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        L.q3tts_assets_text_embedding.argtypes = [C.c_void_p, C.c_int64, C.c_void_p]
+        L.q3tts_assets_tts_pad.argtypes = [C.c_void_p, C.c_void_p]
+        L.q3tts_prompt_build_core.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p,
+                                              C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.q3tts_prompt_build_clone.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32,
+                                               C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.q3tts_sampler_new.restype = C.c_void_p
+        L.q3tts_sampler_new.argtypes = [C.c_float, C.c_int32, C.c_float, C.c_uint64]
+        L.q3tts_sampler_free.argtypes = [C.c_void_p]
+        L.q3tts_sampler_sample.restype = C.c_int32
+        L.q3tts_sampler_sample.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32]
+        L.q3tts_chunker_new.restype = C.c_void_p
+        L.q3tts_chunker_new.argtypes = [DECODE_CB, C.c_void_p]
+        L.q3tts_chunker_free.argtypes = [C.c_void_p]
+        L.q3tts_chunker_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.q3tts_decoder_create.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.q3tts_decoder_destroy.argtypes = [C.c_void_p]
+        L.q3tts_decoder_samples_per_frame.argtypes = [C.c_void_p]
+        L.q3tts_decoder_reset.argtypes = [C.c_void_p, C.c_int32]
+        L.q3tts_decoder_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
+        L.q3tts_mel_frames.argtypes = [C.c_int32]
+        L.q3tts_mel.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.q3tts_tf_open.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.q3tts_tf_close.argtypes = [C.c_void_p]
+        L.q3tts_tf_dims.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
+        L.q3tts_tf_clear.argtypes = [C.c_void_p]
+        L.q3tts_tf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
+        L.q3tts_op_gemv_q8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.q3tts_op_rmsnorm_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.q3tts_op_swiglu_quant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
+        L.q3tts_op_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.q3tts_op_project.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
+        _lib = L
+    return _lib
+
+
+def _p(a):
+    return a.ctypes.data_as(C.c_void_p) if a is not None else None
+
+
+def _chk(rc):
+    if rc != 0:
+        raise Q3Error(lib().q3tts_last_error().decode())
+
+
+def device_count():
+    return lib().q3tts_device_count()
+
+
+class Assets:
+    def __init__(self, path=None, handle=None):
+        self._own = handle is None
+        if handle is None:
+            h = C.c_void_p()
+            _chk(lib().q3tts_assets_open(path.encode(), C.byref(h)))
+            handle = h.value
+        self.h = handle
+
+    def close(self):
+        if self._own and self.h:
+            lib().q3tts_assets_close(self.h)
+        self.h = None
+
+    def codec_embedding(self, q, code):
+        out = np.zeros(2048, np.float32)
+        _chk(lib().q3tts_assets_codec_embedding(self.h, q, code, _p(out)))
+        return out
+
+    def text_embedding(self, tok):
+        out = np.zeros(2048, np.float32)
+        _chk(lib().q3tts_assets_text_embedding(self.h, tok, _p(out)))
+        return out
+
+    def tts_pad(self):
+        out = np.zeros(2048, np.float32)
+        _chk(lib().q3tts_assets_tts_pad(self.h, _p(out)))
+        return out
+
+    def build_core(self, text_ids, lang_id=2055, spk_id=None, spk_emb=None, instr_ids=None, mid=None, max_rows=4096):
+        t = np.ascontiguousarray(text_ids, np.int32)
+        ins = np.ascontiguousarray(instr_ids, np.int32) if instr_ids is not None else None
+        se = np.ascontiguousarray(spk_emb, np.float32) if spk_emb is not None else None
+        md = np.ascontiguousarray(mid, np.float32) if mid is not None else None
+        out = np.zeros((max_rows, 2048), np.float32)
+        n = lib().q3tts_prompt_build_core(self.h, _p(t), t.size, -1 if lang_id is None else lang_id,
+                                          -1 if spk_id is None else spk_id, _p(se), _p(ins), ins.size if ins is not None else 0,
+                                          _p(md), md.shape[0] if md is not None else 0, _p(out), max_rows)
+        if n < 0:
+            raise Q3Error(lib().q3tts_last_error().decode())
+        return out[:n].copy()
+
+    def build_clone(self, text_ids, ref_codes, ref_text_ids, spk_emb, lang_id=2055, instr_ids=None, max_rows=4096):
+        t = np.ascontiguousarray(text_ids, np.int32)
+        rc = np.ascontiguousarray(ref_codes, np.int32)
+        rt = np.ascontiguousarray(ref_text_ids, np.int32)
+        se = np.ascontiguousarray(spk_emb, np.float32)
+        ins = np.ascontiguousarray(instr_ids, np.int32) if instr_ids is not None else None
+        out = np.zeros((max_rows, 2048), np.float32)
+        n = lib().q3tts_prompt_build_clone(self.h, _p(t), t.size, _p(rc), rc.size, _p(rt), rt.size, _p(se), lang_id, _p(ins),
+                                           ins.size if ins is not None else 0, _p(out), max_rows)
+        if n < 0:
+            raise Q3Error(lib().q3tts_last_error().decode())
+        return out[:n].copy()
+
+
+class Sampler:  # LlamaSampler (llama/mod.rs:627-776)
+    def __init__(self, temperature=0.0, top_k=0, top_p=1.0, seed=42):
+        self.h = lib().q3tts_sampler_new(temperature, top_k, top_p, seed)
+
+    def sample(self, logits, start=0, end=None):
+        logits = np.ascontiguousarray(logits, np.float32)
+        return lib().q3tts_sampler_sample(self.h, _p(logits), logits.size, start, logits.size if end is None else end)
+
+    def close(self):
+        if self.h:
+            lib().q3tts_sampler_free(self.h)
+        self.h = None
+
+
+class Chunker:  # engine.rs:495-543
+    def __init__(self):
+        self.calls = []
+
+        def cb(user, codes, n, fin):
+            self.calls.append(([codes[i] for i in range(n)], bool(fin)))
+
+        self._cb = DECODE_CB(cb)
+        self.h = lib().q3tts_chunker_new(self._cb, None)
+
+    def push(self, codes, is_final=False):
+        a = np.ascontiguousarray(codes, np.int64)
+        _chk(lib().q3tts_chunker_push(self.h, _p(a) if a.size else None, a.size, 1 if is_final else 0))
+
+    def close(self):
+        if self.h:
+            lib().q3tts_chunker_free(self.h)
+        self.h = None
+
+
+class Engine:  # TtsEngine (engine.rs:53-169) at the embedding level
+    def __init__(self, model_dir, quant="q8_0", max_batch=1, max_prompt=1024, max_steps=512, load_codec=True, use_graph=True, device=0):
+        p = EngineParams()
+        lib().q3tts_engine_params_default(C.byref(p))
+        self._md = model_dir.encode()
+        self._q = quant.encode()
+        p.model_dir = self._md
+        p.quant = self._q
+        p.device = device
+        p.max_batch = max_batch
+        p.max_prompt = max_prompt
+        p.max_steps = max_steps
+        p.load_codec = 1 if load_codec else 0
+        p.use_graph = 1 if use_graph else 0
+        h = C.c_void_p()
+        _chk(lib().q3tts_engine_create(C.byref(p), C.byref(h)))
+        self.h = h.value
+        self.max_steps = max_steps
+        self.assets = Assets(handle=lib().q3tts_engine_assets(self.h))
+
+    def close(self):
+        if self.h:
+            lib().q3tts_engine_destroy(self.h)
+        self.h = None
+
+    def generate_batch(self, prompts, max_steps=8, temperature=0.0, top_k=40, top_p=0.9, seed=42, mask_eos=True, want_pcm=False,
+                       pcm_per_frame=1920):
+        n = len(prompts)
+        reqs = (Request * n)()
+        keep = []
+        for i, pr in enumerate(prompts):
+            pr = np.ascontiguousarray(pr, np.float32)
+            codes = np.zeros(max_steps * 16, np.int32)
+            pcm = np.zeros(max(max_steps * pcm_per_frame, 1), np.float32) if want_pcm else None
+            keep.append((pr, codes, pcm))
+            r = reqs[i]
+            r.prompt = pr.ctypes.data
+            r.n_prompt = pr.shape[0]
+            r.sampler.temperature = temperature
+            r.sampler.top_k = top_k
+            r.sampler.top_p = top_p
+            r.sampler.has_seed = 1
+            r.sampler.seed = seed
+            r.max_steps = max_steps
+            r.mask_eos = 1 if mask_eos else 0
+            r.codes_out = codes.ctypes.data
+            r.pcm_out = pcm.ctypes.data if pcm is not None else None
+            r.pcm_capacity = pcm.size if pcm is not None else 0
+        _chk(lib().q3tts_generate_batch(self.h, reqs, n, 1 if want_pcm else 0))
+        out = []
+        for i in range(n):
+            nf = reqs[i].n_frames
+            out.append({"codes": keep[i][1][: nf * 16].reshape(nf, 16).copy(),
+                        "pcm": keep[i][2][: reqs[i].n_pcm].copy() if want_pcm else None,
+                        "prefill_ms": reqs[i].prefill_ms, "first_chunk_ms": reqs[i].first_chunk_ms, "total_ms": reqs[i].total_ms})
+        return out
+
+    def stats(self):
+        s = Stats()
+        _chk(lib().q3tts_engine_stats(self.h, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in Stats._fields_}
+
+    def reset_stats(self):
+        lib().q3tts_engine_reset_stats(self.h)
+
+    def set_instrument(self, on):
+        lib().q3tts_engine_set_instrument(self.h, 1 if on else 0)
+
+    def bytes_per_step(self, batch, mean_ctx):
+        return lib().q3tts_engine_bytes_per_step(self.h, batch, mean_ctx)
+
+
+class TfContext:  # LlamaModel + LlamaContext at the embedding level (llama/mod.rs:326-513)
+    def __init__(self, path, n_ctx=4096, max_tok=64):
+        h = C.c_void_p()
+        _chk(lib().q3tts_tf_open(path.encode(), n_ctx, max_tok, C.byref(h)))
+        self.h = h.value
+        d = [C.c_int32() for _ in range(4)]
+        lib().q3tts_tf_dims(self.h, *[C.byref(x) for x in d])
+        self.n_embd, self.n_layer, self.n_head, self.n_vocab = [x.value for x in d]
+
+    def close(self):
+        if self.h:
+            lib().q3tts_tf_close(self.h)
+        self.h = None
+
+    def clear(self):
+        lib().q3tts_tf_clear(self.h)
+
+    def eval(self, x, pos4, row0=0, row1=0):
+        x = np.ascontiguousarray(x, np.float32).reshape(-1, self.n_embd)
+        pos4 = np.ascontiguousarray(pos4, np.int32).reshape(-1, 4)
+        n = x.shape[0]
+        hid = np.zeros((n, self.n_embd), np.float32)
+        logits = np.zeros((n, max(row1 - row0, 1)), np.float32)
+        _chk(lib().q3tts_tf_eval(self.h, _p(x), _p(pos4), n, _p(hid), _p(logits) if row1 > row0 else None, row0, row1))
+        return hid, logits[:, : max(row1 - row0, 0)]
+
+
+class Decoder:  # AudioDecoder (onnx.rs:324-496)
+    def __init__(self, path, n_streams=1):
+        h = C.c_void_p()
+        _chk(lib().q3tts_decoder_create(path.encode(), n_streams, C.byref(h)))
+        self.h = h.value
+        self.spf = lib().q3tts_decoder_samples_per_frame(self.h)
+
+    def close(self):
+        if self.h:
+            lib().q3tts_decoder_destroy(self.h)
+        self.h = None
+
+    def reset(self, stream=0):
+        _chk(lib().q3tts_decoder_reset(self.h, stream))
+
+    def decode(self, codes, is_last=False, stream=0):
+        codes = np.ascontiguousarray(codes, np.int64).reshape(-1, 16)
+        wav = np.zeros(codes.shape[0] * self.spf, np.float32)
+        valid = C.c_int64(0)
+        _chk(lib().q3tts_decoder_decode(self.h, stream, _p(codes), codes.shape[0], 1 if is_last else 0, _p(wav), C.byref(valid)))
+        return wav[: valid.value]
+
+
+def op_gemv_q8(w_raw, n, k, xq, xd, lpr=0):
+    xq = np.ascontiguousarray(xq, np.int8).reshape(-1, k)
+    xd = np.ascontiguousarray(xd, np.uint16).reshape(-1, k // 32)
+    w_raw = np.ascontiguousarray(w_raw, np.uint8)
+    y = np.zeros((xq.shape[0], n), np.float32)
+    _chk(lib().q3tts_op_gemv_q8(_p(w_raw), n, k, _p(xq), _p(xd), xq.shape[0], _p(y), lpr))
+    return y
+
+
+def op_rmsnorm_quant(x, g, eps=1e-6):
+    x = np.ascontiguousarray(x, np.float32)
+    x2 = x.reshape(-1, x.shape[-1])
+    d = x2.shape[1]
+    g = np.ascontiguousarray(g, np.float32)
+    xq = np.zeros(x2.shape, np.int8)
+    xd = np.zeros((x2.shape[0], d // 32), np.uint16)
+    xn = np.zeros(x2.shape, np.float32)
+    _chk(lib().q3tts_op_rmsnorm_quant(_p(x2), _p(g), d, x2.shape[0], eps, _p(xq), _p(xd), _p(xn)))
+    return xq, xd, xn
+
+
+def op_swiglu_quant(gu, ff):
+    gu = np.ascontiguousarray(gu, np.float32).reshape(-1, 2 * ff)
+    aq = np.zeros((gu.shape[0], ff), np.int8)
+    ad = np.zeros((gu.shape[0], ff // 32), np.uint16)
+    _chk(lib().q3tts_op_swiglu_quant(_p(gu), ff, gu.shape[0], _p(aq), _p(ad)))
+    return aq, ad
+
+
+def op_argmax(logits, start, end, mask_idx=-1):
+    logits = np.ascontiguousarray(logits, np.float32)
+    out = np.zeros(1, np.int32)
+    _chk(lib().q3tts_op_argmax(_p(logits), logits.size, start, end, mask_idx, _p(out)))
+    return int(out[0])
+
+
+def op_project(x, w, b):
+    x = np.ascontiguousarray(x, np.float32)
+    w = np.ascontiguousarray(w, np.float32)
+    b = np.ascontiguousarray(b, np.float32)
+    y = np.zeros(b.size, np.float32)
+    _chk(lib().q3tts_op_project(_p(x), _p(w), _p(b), x.size, b.size, _p(y)))
+    return y
+
+
+def mel(audio):
+    audio = np.ascontiguousarray(audio, np.float32)
+    n = lib().q3tts_mel_frames(audio.size)
+    out = np.zeros((n, 128), np.float32)
+    _chk(lib().q3tts_mel(_p(audio), audio.size, _p(out)))
+    return out
