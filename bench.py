@@ -1,0 +1,209 @@
+#!/usr/bin/env python3
+"""bench.py -- headline benchmark of the MI355X-native Qwen3-TTS hot path (contract in the task prompt, part 4).
+
+Workload (config C2 of BASELINE.json / SURVEY.md 8d): single utterance per GPU, "Q3TTS-1.7B-synth" Q8_0 weights
+(seeded random, written on the box by tools/q3synth), speaker = vivian, preset prompt with 32 synthetic text ids
+(43 prompt rows), greedy (temperature 0, seed 42), EOS masked so every run emits exactly 4*K frames.
+One "step" = one 4-frame streaming step (4 x [talker + 15-pass predictor] hipGraph replays + one codec chunk).
+The timed region is one whole utterance of K steps: prompt upload + prefill + K steps, inputs resident in HBM
+except the 352 KB prompt (the span the reference's CLI times, src/bin/qwen3_tts.rs:144-153).
+value = audio seconds generated per wall second, summed over ranks (weak scaling: one utterance per GPU).
+"""
+import argparse
+import json
+import os
+import statistics
+import subprocess
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, os.path.join(ROOT, "qwen3-tts-rust_amd", "python"))
+
+FRAME_SEC = 1920.0 / 24000.0  # 12.5 Hz codec frames [EXT]
+HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
+
+
+_T0 = time.time()
+
+
+def log(msg):
+    print("[bench %.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def ensure_model(model_dir, quant):
+    marker = os.path.join(model_dir, ".complete_" + quant)
+    if os.path.exists(marker):
+        return
+    tool = os.path.join(ROOT, "tools", "q3synth")
+    if not os.path.exists(tool):
+        subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "tools")])
+    subprocess.check_call([tool, "--out", model_dir, "--preset", "full", "--quant", quant, "--seed", "1234"])
+    open(marker, "w").write("ok")
+
+
+def build_prompt(assets, spk_emb, n_text=32, seed=42):
+    rng = np.random.default_rng(seed)
+    text = rng.integers(0, 4000, n_text).astype(np.int32)
+    return assets.build_core(text, lang_id=2055, spk_emb=spk_emb)
+
+
+def cpu_baseline(model_dir, quant_dir, prompt, threads=4):
+    """Oracle (CPU restatement, oracle/) timed with the reference's threading (llama threads capped at 4,
+    /root/reference/src/models/llama/mod.rs:420-428): a BOUNDED sample, extrapolated to the 128-frame utterance."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import q3oracle as O
+    eng = O.Engine(os.path.join(model_dir, quant_dir), None, threads)
+    n_pre, n_fr = 16, 12
+    eng.generate(prompt[-2:], max_steps=0)  # page the mmapped weights in (untimed)
+    t0 = time.time()
+    eng.generate(prompt[-n_pre:], max_steps=0)
+    t_pre = (time.time() - t0) / n_pre  # seconds per prefill token
+    t0 = time.time()
+    eng.generate(prompt[-n_pre:], max_steps=n_fr)
+    t_frame = (time.time() - t0 - t_pre * n_pre) / n_fr
+    eng.close()
+    frames = 128
+    total = t_pre * prompt.shape[0] + t_frame * frames
+    return {"value": frames * FRAME_SEC / total, "unit": "audio_s/s", "cores": threads, "kind": "port",
+            "rtf": total / (frames * FRAME_SEC),
+            "sample": "oracle AR loop (no codec): %d prefill tokens + %d frames timed (%.3f s/token, %.3f s/frame), "
+                      "extrapolated to %d prompt rows + %d frames" % (n_pre, n_fr, t_pre, t_frame, prompt.shape[0], frames)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--quant", default="q8_0")
+    ap.add_argument("--model-dir", default=os.environ.get("Q3_BENCH_MODEL", "/tmp/q3tts_synth_full"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-codec", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    import torch
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        torch.cuda.set_device(local_rank)
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cuda", local_rank)
+
+    log("torch imported")
+    if local_rank == 0:
+        ensure_model(args.model_dir, args.quant)
+    log("model ready")
+    if dist:
+        dist.barrier()
+
+    import q3tts as Q
+    quant_dir = {"q8_0": "gguf_q8_0", "q5_k_m": "gguf_q5_k_m", "bf16": "gguf_bf16"}.get(args.quant, "gguf")
+    codec_path = os.path.join(args.model_dir, "onnx", "q3tts_codec.gguf")
+    have_codec = (not args.no_codec) and os.path.exists(codec_path)
+    max_frames = 4 * max(args.steps, args.warmup, 2)
+    try:
+        eng = Q.Engine(args.model_dir, args.quant, max_batch=1, max_prompt=1024, max_steps=max_frames, load_codec=have_codec,
+                       device=local_rank)
+    except Q.Q3Error as ex:
+        if have_codec and "codec" in str(ex):
+            have_codec = False
+            eng = Q.Engine(args.model_dir, args.quant, max_batch=1, max_prompt=1024, max_steps=max_frames, load_codec=False,
+                           device=local_rank)
+        else:
+            raise
+
+    # speaker embedding: rank 0 owns the voice file; the ONE collective of the path is its broadcast over RCCL/xGMI
+    spk = torch.zeros(2048, dtype=torch.float32, device=dev)
+    if rank == 0:
+        v = json.load(open(os.path.join(ROOT, "tests", "golden", "speakers", "vivian.json")))
+        spk.copy_(torch.tensor(v["spk_emb"], dtype=torch.float32))
+    if dist:
+        dist.broadcast(spk, src=0)
+    spk_emb = spk.cpu().numpy()
+    prompt = build_prompt(eng.assets, spk_emb)
+    log("engine up, prompt rows %d" % prompt.shape[0])
+
+    def run(steps, pcm):
+        return eng.generate_batch([prompt], max_steps=4 * steps, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)[0]
+
+    if args.warmup > 0:
+        run(args.warmup, have_codec)
+    log("warmup done")
+    eng.reset_stats()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = run(args.steps, have_codec)
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if dist:
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    elapsed = float(t.item())
+    st = eng.stats()
+    log("timed region done: %.3f s" % elapsed)
+    n_frames = res["codes"].shape[0]
+    assert n_frames == 4 * args.steps, "EOS-masked run must emit exactly 4*steps frames"
+    audio_s = n_frames * FRAME_SEC
+
+    out = None
+    if rank == 0:
+        # first-chunk latency (submit -> first PCM chunk available, engine.rs:522-523 analogue): p50 over short utterances
+        lat = []
+        for _ in range(5):
+            r = run(2, have_codec)
+            lat.append(r["first_chunk_ms"] if have_codec else r["prefill_ms"] + (r["total_ms"] - r["prefill_ms"]) / 2.0)
+        log("latency runs done")
+        # instrumented leg: same K steps, eager launches with a HIP-event pair around every k_gemv_q8 launch
+        eng.reset_stats()
+        eng.set_instrument(True)
+        run(args.steps, False)
+        eng.set_instrument(False)
+        si = eng.stats()
+        mean_ctx = prompt.shape[0] + n_frames / 2.0
+        step_bytes = eng.bytes_per_step(1, mean_ctx)
+        gemv_gbs = si["gemv_bytes"] / (si["gemv_ms"] * 1e-3) / 1e9 if si["gemv_ms"] > 0 else 0.0
+        frame_ms = st["frame_loop_ms"] / max(st["frames"], 1)
+        out = {
+            "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
+            "value": world * audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "i8", "data": "synthetic",
+            "config": {"workload": "C2 single utterance per GPU, Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
+                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": 1,
+                       "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
+            "rtf": elapsed / audio_s,
+            "first_chunk_ms_p50": statistics.median(lat),
+            "decode_ms_per_frame": frame_ms,
+            "prefill_ms": st["prefill_ms"],
+            "codec_ms_per_chunk": (st["codec_ms"] / st["codec_calls"]) if st["codec_calls"] else None,
+            "frame_hbm_frac": (step_bytes / (frame_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if frame_ms > 0 else None,
+            "roofline": {"bound": "hbm", "kernel": "k_gemv_q8 (all instantiations; %d launches)" % si["gemv_launches"],
+                         "achieved": gemv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gemv_gbs / HBM_PEAK_GBS,
+                         "avg_launch_us": 1e3 * si["gemv_ms"] / max(si["gemv_launches"], 1),
+                         "bytes_per_launch": si["gemv_bytes"] / max(si["gemv_launches"], 1), "traffic": None},
+        }
+        log("instrumented leg done")
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                out["cpu_baseline"] = cpu_baseline(args.model_dir, quant_dir, prompt)
+            except Exception as ex:  # the oracle is optional test infrastructure; report, do not hide
+                out["cpu_baseline"] = {"value": None, "unit": "audio_s/s", "cores": 4, "kind": "port", "sample": "failed: %s" % ex}
+        print(json.dumps(out))
+    eng.close()
+    if dist:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

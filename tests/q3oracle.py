@@ -19,6 +19,8 @@ def build():
 def lib():
     global _LIB
     if _LIB is None:
+        os.environ.setdefault("OMP_NUM_THREADS", "8")       # GPU boxes expose far more cores than their CPU share
+        os.environ.setdefault("OMP_WAIT_POLICY", "passive")
         path = os.path.join(ROOT, "oracle", "libq3oracle.so")
         if not os.path.exists(path):
             build()

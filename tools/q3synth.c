@@ -19,6 +19,9 @@
 #include <stdint.h>
 #include <math.h>
 #include <sys/stat.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include "../include/q3tts_spec.h"
 
 /* ---------- counter-based RNG: approx N(0,1) from one 64-bit hash (Irwin-Hall of 4x16 bit) ---------- */
@@ -212,8 +215,15 @@ static int gw_write(gw* g, const char* path) {
     for (int i = 0; i < g->nt; i++) {
         tdesc* t = &g->t[i];
         int64_t k = t->ne[0], rows = t->ne[1] * t->ne[2];
+        if (t->type == Q3_T_F32 || t->type == Q3_T_F16 || t->type == Q3_T_BF16) {
+            /* unquantised: row structure is irrelevant, use long pseudo-rows (few, large parallel regions) */
+            int64_t total = k * rows;
+            int64_t pk = 4096;
+            while (total % pk) pk >>= 1;
+            k = pk; rows = total / pk;
+        }
         size_t rb = row_bytes(t->type, k);
-        const int64_t chunk = 4096; /* rows per chunk */
+        const int64_t chunk = (int64_t)(((size_t)64 << 20) / (rb ? rb : 1)) + 1; /* ~64 MiB of output per parallel region */
         uint8_t* buf = (uint8_t*)malloc(rb * (size_t)(rows < chunk ? rows : chunk));
         for (int64_t r0 = 0; r0 < rows; r0 += chunk) {
             int64_t rn = rows - r0 < chunk ? rows - r0 : chunk;
@@ -406,6 +416,9 @@ int main(int argc, char** argv) {
         else { fprintf(stderr, "usage: q3synth --out DIR [--preset full|tiny] [--quant q8_0|q5_k_m|bf16|f16|f32] [--seed N] [--text-rows N] [--what mask]\n"); return 2; }
     }
     if (!out) { fprintf(stderr, "--out required\n"); return 2; }
+#ifdef _OPENMP
+    if (!getenv("OMP_NUM_THREADS")) { int n = omp_get_num_procs(); omp_set_num_threads(n > 8 ? 8 : n); } /* cgroup CPU shares are smaller than the core count */
+#endif
     tfcfg talker, pred; ccfg codec;
     if (!strcmp(preset, "full")) { /* SURVEY 8d "Q3TTS-1.7B-synth" [EXT dims] */
         talker = (tfcfg){ 2048, 28, 16, 8, 6144, 3072, 1 };
