@@ -1,11 +1,585 @@
-// codec.hip -- placeholder until the HIP codec decoder lands in this round (fails loudly, never falls back).
+// codec.hip -- streaming codec decoder on MI355X: codes -> 24 kHz PCM, "Q3TTS-codec-synth" (see codec.h).
+//
+// Every convolution / linear is one implicit-GEMM kernel on exact-f32 MFMA (v_mfma_f32_32x32x2_f32; bf16 would
+// not hold the 1e-4 RMS PCM bar).  Activations are time-major [T][C]; a causal conv with k taps and dilation d
+// reads its A operand straight from an "extended" buffer whose first (k-1)*d rows are the stream's history, so
+// streaming state lives on the device and chunked decoding equals a full-sequence pass exactly.
+// Transposed convs (k = 2*stride) are the same GEMM with two taps and N = stride*cout columns (r, co).
 #include "codec.h"
+#include "gguf.h"
+#include <cmath>
+#include <map>
+
 namespace q3 {
-struct CodecDecoder::Impl {};
-CodecDecoder::CodecDecoder(const std::string&, int, int) { throw Error("HIP codec decoder not built yet"); }
-CodecDecoder::~CodecDecoder() {}
-int CodecDecoder::samples_per_frame() const { return 0; }
-void CodecDecoder::reset(int) {}
-int CodecDecoder::decode(hipStream_t, int, const int64_t*, int, bool, float*) { return -1; }
-double CodecDecoder::flops_per_frame() const { return 0; }
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RES_SCALE = 2, EPI_RES = 3 };
+
+struct GemmArgs {
+    const float* A; int lda;        // A rows: time-major activations (extended buffer), row stride lda floats
+    int cin, dil;                   // K index kk -> tap j = kk / cin, channel ci = kk % cin ; A row = m + j*dil
+    const float* W;                 // [N][K] row-major (rearranged at load)
+    const float* bias;              // [N] or null
+    float* out; int ldo;            // out[m][n]
+    int M, N, K;
+    int epi; const float* res; int ldr; const float* scale; // EPI_RES_SCALE: out = res + scale[n]*(acc+bias); EPI_RES: res + acc+bias
+};
+
+// Workgroup = 4 waves; WM = waves along M.  Tile (32*WM) x (32*(4/WM)), BK = 16, LDS tiles stored k-major so the
+// MFMA fragment reads (lane -> 32 consecutive m or n) are conflict-free.
+template <int WM>
+__global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
+    constexpr int WN = 4 / WM, BM = 32 * WM, BN = 32 * WN, BK = 16;
+    __shared__ float As[BK][BM];
+    __shared__ float Bs[BK][BN];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave / WN, wn = wave % WN;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+        const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
+        // A tile: BM rows x 16 floats; thread -> (row = e % BM, quad = e / BM)
+        for (int e = tid; e < BM * 4; e += 256) {
+            const int r = e % BM, qd = e / BM;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < g.M) v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + r + j * g.dil) * g.lda + ci0 + 4 * qd);
+            As[4 * qd + 0][r] = v.x; As[4 * qd + 1][r] = v.y; As[4 * qd + 2][r] = v.z; As[4 * qd + 3][r] = v.w;
+        }
+        for (int e = tid; e < BN * 4; e += 256) {
+            const int r = e % BN, qd = e / BN;
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (n0 + r < g.N) v = *reinterpret_cast<const float4*>(g.W + (size_t)(n0 + r) * g.K + k0 + 4 * qd);
+            Bs[4 * qd + 0][r] = v.x; Bs[4 * qd + 1][r] = v.y; Bs[4 * qd + 2][r] = v.z; Bs[4 * qd + 3][r] = v.w;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 2) {
+            const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float b = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+        const float bv = g.bias ? g.bias[col] : 0.0f;
+        const float sc = (g.epi == EPI_RES_SCALE) ? g.scale[col] : 1.0f;
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float v = acc[r] + bv;
+                if (g.epi == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+                else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + col] + sc * v;
+                else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + col] + v;
+                g.out[(size_t)row * g.ldo + col] = v;
+            }
+        }
+    }
 }
+static void gemm(hipStream_t st, const GemmArgs& g) {
+    if (g.M <= 32) hipLaunchKernelGGL((k_conv_gemm<1>), dim3((g.N + 127) / 128, (g.M + 31) / 32), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_conv_gemm<2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
+}
+
+// ---------------- small elementwise / reduction kernels ----------------
+__global__ void k_rvq_sum(const int64_t* __restrict__ codes, const float* const* __restrict__ cb, int n_q, int cb_size, int cb_dim,
+                          float* __restrict__ out, int ldo) {
+    const int t = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
+    if (d >= cb_dim) return;
+    float acc = 0.0f;
+    for (int q = 0; q < n_q; q++) {
+        long long c = codes[(size_t)t * n_q + q];
+        c = c < 0 ? 0 : (c >= cb_size ? cb_size - 1 : c);
+        acc += cb[q][(size_t)c * cb_dim + d];
+    }
+    out[(size_t)t * ldo + d] = acc;
+}
+__global__ void __launch_bounds__(256) k_rmsnorm_rows(const float* __restrict__ x, int ldx, const float* __restrict__ g, int C, float eps,
+                                                      float* __restrict__ y, int ldy) {
+    __shared__ float red[4];
+    const int t = blockIdx.x;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float v = x[(size_t)t * ldx + c]; s += v * v; }
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float tot = red[0] + red[1] + red[2] + red[3];
+    const float sc = 1.0f / sqrtf(tot / (float)C + eps);
+    for (int c = threadIdx.x; c < C; c += 256) y[(size_t)t * ldy + c] = x[(size_t)t * ldx + c] * sc * g[c];
+}
+__global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict__ x, int ldx, const float* __restrict__ w,
+                                                        const float* __restrict__ b, int C, float eps, float* __restrict__ y, int ldy) {
+    __shared__ float red[8];
+    const int t = blockIdx.x;
+    float s = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) s += x[(size_t)t * ldx + c];
+    for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    const float mu = (red[0] + red[1] + red[2] + red[3]) / (float)C;
+    float v = 0.0f;
+    for (int c = threadIdx.x; c < C; c += 256) { const float dlt = x[(size_t)t * ldx + c] - mu; v += dlt * dlt; }
+    for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+    if ((threadIdx.x & 63) == 0) red[4 + (threadIdx.x >> 6)] = v;
+    __syncthreads();
+    const float var = (red[4] + red[5] + red[6] + red[7]) / (float)C;
+    const float inv = 1.0f / sqrtf(var + eps);
+    for (int c = threadIdx.x; c < C; c += 256) y[(size_t)t * ldy + c] = (x[(size_t)t * ldx + c] - mu) * inv * w[c] + b[c];
+}
+// NeoX RoPE on q and k inside a packed [T][3*H] qkv buffer (head_dim hd), absolute position pos0 + t
+__global__ void k_codec_rope(float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ cs, const float* __restrict__ sn,
+                             long long pos0, int max_pos) {
+    const int t = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, half = hd / 2;
+    if (e >= H / 2) return;
+    const int head = e / half, i = e % half;
+    long long p = pos0 + t;
+    if (p >= max_pos) p = max_pos - 1;
+    const float c = cs[(size_t)p * half + i], s = sn[(size_t)p * half + i];
+    for (int which = 0; which < 2; which++) {
+        float* v = qkv + (size_t)t * ld + which * H + head * hd;
+        const float a = v[i], b = v[i + half];
+        v[i] = a * c - b * s; v[i + half] = b * c + a * s;
+    }
+}
+// append new K,V rows to the layer's history buffers: kbuf/vbuf [(W-1)+Tmax][H]
+__global__ void k_kv_append(const float* __restrict__ qkv, int ld, int H, float* __restrict__ kbuf, float* __restrict__ vbuf, int kv_len) {
+    const int t = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= H) return;
+    kbuf[(size_t)(kv_len + t) * H + c] = qkv[(size_t)t * ld + H + c];
+    vbuf[(size_t)(kv_len + t) * H + c] = qkv[(size_t)t * ld + 2 * H + c];
+}
+// sliding-window attention: one wave per (head, t); keys j in [max(0, kv_len+t-W+1), kv_len+t]
+__global__ void __launch_bounds__(64) k_codec_attn(const float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ kbuf,
+                                                   const float* __restrict__ vbuf, int kv_len, int W, float* __restrict__ out, int ldo) {
+    __shared__ float p_s[128];
+    __shared__ float q_s[128];
+    const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
+    const int j1 = kv_len + t, j0 = (j1 - (W - 1)) > 0 ? (j1 - (W - 1)) : 0, nk = j1 - j0 + 1;
+    for (int d = lane; d < hd; d += 64) q_s[d] = qkv[(size_t)t * ld + head * hd + d];
+    __syncthreads();
+    const float scale = 1.0f / sqrtf((float)hd);
+    float mx = -INFINITY;
+    for (int jj = lane; jj < nk; jj += 64) {
+        const float* kr = kbuf + (size_t)(j0 + jj) * H + head * hd;
+        float a = 0.0f;
+        for (int d = 0; d < hd; d++) a += q_s[d] * kr[d];
+        a *= scale;
+        p_s[jj] = a;
+        mx = fmaxf(mx, a);
+    }
+    for (int o = 32; o >= 1; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    float den = 0.0f;
+    for (int jj = lane; jj < nk; jj += 64) { const float e = expf(p_s[jj] - mx); p_s[jj] = e; den += e; }
+    for (int o = 32; o >= 1; o >>= 1) den += __shfl_xor(den, o);
+    __syncthreads();
+    for (int d = lane; d < hd; d += 64) {
+        float a = 0.0f;
+        for (int jj = 0; jj < nk; jj++) a += p_s[jj] * vbuf[(size_t)(j0 + jj) * H + head * hd + d];
+        out[(size_t)t * ldo + head * hd + d] = a / den;
+    }
+}
+__global__ void k_swiglu_rows(const float* __restrict__ gu, int ff, float* __restrict__ out) { // gu [T][2ff] -> out [T][ff]
+    const int t = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= ff) return;
+    const float g = gu[(size_t)t * 2 * ff + c], u = gu[(size_t)t * 2 * ff + ff + c];
+    out[(size_t)t * ff + c] = (g / (1.0f + expf(-g))) * u;
+}
+// depthwise causal conv k=7: in_ext [6+T][C], w [C][7]
+__global__ void k_dwconv7(const float* __restrict__ in_ext, int C, const float* __restrict__ w, const float* __restrict__ b,
+                          float* __restrict__ out) {
+    const int t = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+    if (c >= C) return;
+    float a = b[c];
+#pragma unroll
+    for (int j = 0; j < 7; j++) a += w[c * 7 + j] * in_ext[(size_t)(t + j) * C + c];
+    out[(size_t)t * C + c] = a;
+}
+// y = x + inv_eb[c] * sin^2(x*ea[c]); src [T][C] -> dst rows (dst may equal src)
+__global__ void k_snake(const float* __restrict__ src, float* __restrict__ dst, int C, const float* __restrict__ ea,
+                        const float* __restrict__ inv_eb, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int c = (int)(i % C);
+    const float v = src[i];
+    const float s = sinf(v * ea[c]);
+    dst[i] = v + inv_eb[c] * (s * s);
+}
+__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) dst[i] = src[i];
+}
+// final conv (cout = 1): out[t] = clamp(b + sum_{j,c} w[j*C+c] * in_ext[t+j][c])
+__global__ void __launch_bounds__(256) k_conv_out(const float* __restrict__ in_ext, int C, const float* __restrict__ w, float bias,
+                                                  float* __restrict__ pcm, int T) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= T) return;
+    float a = bias;
+    for (int j = 0; j < 7; j++)
+        for (int c = 0; c < C; c++) a += w[j * C + c] * in_ext[(size_t)(t + j) * C + c];
+    pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+}
+
+// ---------------- host side ----------------
+struct ConvW { DevBuf<float> w, b; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
+struct Snake { DevBuf<float> ea, inv_eb; int C = 0; };
+struct Ext { // per-stream extended activation buffer: H history rows then up to Tmax rows of C floats
+    std::vector<DevBuf<float>> buf; int H = 0, C = 0, Tmax = 0;
+    float* base(int s) { return buf[s].p; }
+    float* cur(int s) { return buf[s].p + (size_t)H * C; }
+};
+
+struct CodecDecoder::Impl {
+    int n_q, cb_size, cb_dim, hidden, n_layers, n_heads, head_dim, ffn, window, n_up, dec_dim, n_dec;
+    int up_ratios[4], dec_rates[8];
+    float rope_base, eps;
+    int n_streams, max_frames, max_pos = 8192;
+    std::vector<DevBuf<float>> codebooks; DevBuf<const float*> d_cb_ptrs;
+    ConvW pre_conv;
+    struct TfL { DevBuf<float> attn_norm, ffn_norm, ls_attn, ls_ffn; ConvW wqkv, wo, wgu, wdown; };
+    std::vector<TfL> tf; DevBuf<float> tf_norm, rope_c, rope_s;
+    struct Up { ConvW ct, pw1, pw2; DevBuf<float> dw_w, dw_b, ln_w, ln_b, gamma; };
+    std::vector<Up> up;
+    ConvW conv_in;
+    struct RU { Snake s1, s2; ConvW c1, c2; };
+    struct Blk { Snake snake; ConvW ct; RU ru[3]; int cin, cout, rate; };
+    std::vector<Blk> blk;
+    Snake snake_out; DevBuf<float> conv_out_w; float conv_out_b = 0;
+    // per-stream state
+    Ext z_ext, convin_ext, out_ext; std::vector<Ext> dw_ext, ct_ext; std::vector<std::vector<Ext>> ru_ext;
+    std::vector<std::vector<DevBuf<float>>> kbuf, vbuf; // [stream][layer]
+    std::vector<int> kv_len; std::vector<long long> n_seen;
+    // scratch (shared by streams; one decode at a time)
+    DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm; DevBuf<int64_t> d_codes;
+    double flops_frame = 0;
+
+    static std::vector<float> tensor(const Gguf& g, const std::string& name) {
+        const GgufTensor& t = g.need(name);
+        Q3_CHECK(t.type == Q3_T_F32, "codec tensor not F32: " + name);
+        const float* p = reinterpret_cast<const float*>(t.data);
+        return std::vector<float>(p, p + t.nbytes / 4);
+    }
+    static void up_f(DevBuf<float>& d, const std::vector<float>& v) { d.alloc(v.size()); d.upload(v.data(), v.size()); }
+    // causal conv weight [cout][cin][k] -> Wr[co][j*cin + ci]
+    void make_conv(ConvW& c, const Gguf& g, const std::string& wn, const std::string& bn, int cout, int cin, int k, int dil) {
+        auto w = tensor(g, wn);
+        Q3_CHECK((int64_t)w.size() == (int64_t)cout * cin * k && cin % 16 == 0, "conv shape " + wn);
+        std::vector<float> r((size_t)cout * cin * k);
+        for (int co = 0; co < cout; co++) for (int ci = 0; ci < cin; ci++) for (int j = 0; j < k; j++)
+            r[((size_t)co * k + j) * cin + ci] = w[((size_t)co * cin + ci) * k + j];
+        up_f(c.w, r);
+        if (!bn.empty()) up_f(c.b, tensor(g, bn));
+        c.N = cout; c.K = cin * k; c.cin = cin; c.taps = k; c.dil = dil;
+    }
+    void make_linear(ConvW& c, const std::vector<float>& w, int N, int K) { up_f(c.w, w); c.N = N; c.K = K; c.cin = K; c.taps = 1; c.dil = 1; }
+    // transposed conv weight [cin][cout][k], stride s (k == 2s or k == s) -> Wr[(r,co)][j*cin+ci], tap 0 = previous frame
+    void make_convt(ConvW& c, const Gguf& g, const std::string& wn, const std::string& bn, int cin, int cout, int k, int s) {
+        auto w = tensor(g, wn);
+        auto b = tensor(g, bn);
+        Q3_CHECK((int64_t)w.size() == (int64_t)cin * cout * k && (k == 2 * s || k == s) && cin % 16 == 0, "convT shape " + wn);
+        const int taps = k / s;
+        std::vector<float> r((size_t)s * cout * taps * cin), br((size_t)s * cout);
+        for (int rr = 0; rr < s; rr++) for (int co = 0; co < cout; co++) {
+            br[(size_t)rr * cout + co] = b[co];
+            for (int ci = 0; ci < cin; ci++) {
+                if (taps == 2) { // A row = [x[t-1] ; x[t]]
+                    r[((size_t)(rr * cout + co) * 2 + 0) * cin + ci] = w[((size_t)ci * cout + co) * k + rr + s];
+                    r[((size_t)(rr * cout + co) * 2 + 1) * cin + ci] = w[((size_t)ci * cout + co) * k + rr];
+                } else r[(size_t)(rr * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * k + rr];
+            }
+        }
+        up_f(c.w, r); up_f(c.b, br);
+        c.N = s * cout; c.K = taps * cin; c.cin = cin; c.taps = taps; c.dil = 1;
+    }
+    void make_snake(Snake& s, const Gguf& g, const std::string& an, const std::string& bn, int C) {
+        auto a = tensor(g, an), b = tensor(g, bn);
+        std::vector<float> ea(C), ib(C);
+        for (int i = 0; i < C; i++) { ea[i] = expf(a[i]); ib[i] = 1.0f / (expf(b[i]) + 1e-9f); }
+        up_f(s.ea, ea); up_f(s.inv_eb, ib); s.C = C;
+    }
+    void make_ext(Ext& e, int H, int C, int Tmax) {
+        e.H = H; e.C = C; e.Tmax = Tmax;
+        e.buf.resize(n_streams);
+        for (auto& b : e.buf) { b.alloc((size_t)(H + Tmax) * C); b.zero(); }
+    }
+    void run_conv(hipStream_t st, const ConvW& c, const float* A, int lda, int M, float* out, int ldo, int epi = EPI_NONE,
+                  const float* res = nullptr, int ldr = 0, const float* scale = nullptr) {
+        GemmArgs g{};
+        g.A = A; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out; g.ldo = ldo;
+        g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res; g.ldr = ldr; g.scale = scale;
+        gemm(st, g);
+    }
+    // move the last H rows of an extended buffer (rows [T, T+H)) to its front
+    void shift(hipStream_t st, Ext& e, int s, int T) {
+        if (e.H == 0) return;
+        const size_t n = (size_t)e.H * e.C;
+        float* b = e.base(s);
+        if (T >= e.H) hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, b, n);
+        else {
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, tmp_hist.p, n);
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp_hist.p, b, n);
+        }
+    }
+    void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int T) {
+        const size_t n = (size_t)T * s.C;
+        hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n);
+    }
+};
+
+CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames) : impl_(new Impl()) {
+    Impl& m = *impl_;
+    Gguf g(path);
+    m.n_streams = n_streams; m.max_frames = max_frames;
+    m.n_q = (int)g.kv_int("codec.n_codebooks", 16); m.cb_size = (int)g.kv_int("codec.codebook_size", 2048);
+    m.cb_dim = (int)g.kv_int("codec.codebook_dim", 512); m.hidden = (int)g.kv_int("codec.hidden", 1024);
+    m.n_layers = (int)g.kv_int("codec.n_layers", 8); m.n_heads = (int)g.kv_int("codec.n_heads", 16);
+    m.head_dim = (int)g.kv_int("codec.head_dim", 64); m.ffn = (int)g.kv_int("codec.ffn", 3072);
+    m.window = (int)g.kv_int("codec.window", 72); m.dec_dim = (int)g.kv_int("codec.dec_dim", 1536);
+    m.rope_base = (float)g.kv_float("codec.rope_base", 10000.0); m.eps = (float)g.kv_float("codec.eps", 1e-5);
+    m.n_up = (int)g.kv_int("codec.n_up", 2); m.n_dec = (int)g.kv_int("codec.n_dec", 4);
+    static const int def_rates[8] = {8, 5, 4, 3, 2, 2, 2, 2};
+    for (int i = 0; i < m.n_up; i++) m.up_ratios[i] = (int)g.kv_int("codec.up_ratio." + std::to_string(i), 2);
+    for (int i = 0; i < m.n_dec; i++) m.dec_rates[i] = (int)g.kv_int("codec.dec_rate." + std::to_string(i), def_rates[i]);
+    const int H = m.hidden, A = m.n_heads * m.head_dim;
+    Q3_CHECK(A == H && m.head_dim <= 128 && m.window <= 128 && m.cb_dim % 16 == 0 && H % 16 == 0 && m.ffn % 16 == 0, "unsupported codec dims");
+    std::vector<const float*> cbp;
+    m.codebooks.resize(m.n_q);
+    for (int q = 0; q < m.n_q; q++) { Impl::up_f(m.codebooks[q], Impl::tensor(g, "codec.codebook." + std::to_string(q))); cbp.push_back(m.codebooks[q].p); }
+    m.d_cb_ptrs.alloc(m.n_q); m.d_cb_ptrs.upload(cbp.data(), m.n_q);
+    m.make_conv(m.pre_conv, g, "codec.pre_conv.weight", "codec.pre_conv.bias", H, m.cb_dim, 3, 1);
+    m.tf.resize(m.n_layers);
+    double fl = 0;
+    fl += 2.0 * H * m.cb_dim * 3;
+    for (int l = 0; l < m.n_layers; l++) {
+        auto& L = m.tf[l];
+        const std::string p = "codec.tf." + std::to_string(l) + ".";
+        Impl::up_f(L.attn_norm, Impl::tensor(g, p + "attn_norm")); Impl::up_f(L.ffn_norm, Impl::tensor(g, p + "ffn_norm"));
+        Impl::up_f(L.ls_attn, Impl::tensor(g, p + "ls_attn")); Impl::up_f(L.ls_ffn, Impl::tensor(g, p + "ls_ffn"));
+        auto wq = Impl::tensor(g, p + "wq"), wk = Impl::tensor(g, p + "wk"), wv = Impl::tensor(g, p + "wv");
+        std::vector<float> qkv; qkv.insert(qkv.end(), wq.begin(), wq.end()); qkv.insert(qkv.end(), wk.begin(), wk.end()); qkv.insert(qkv.end(), wv.begin(), wv.end());
+        m.make_linear(L.wqkv, qkv, 3 * H, H);
+        m.make_linear(L.wo, Impl::tensor(g, p + "wo"), H, A);
+        auto wg = Impl::tensor(g, p + "w_gate"), wu = Impl::tensor(g, p + "w_up");
+        std::vector<float> gu; gu.insert(gu.end(), wg.begin(), wg.end()); gu.insert(gu.end(), wu.begin(), wu.end());
+        m.make_linear(L.wgu, gu, 2 * m.ffn, H);
+        m.make_linear(L.wdown, Impl::tensor(g, p + "w_down"), H, m.ffn);
+        fl += 2.0 * (4.0 * H * H + 3.0 * H * m.ffn);
+    }
+    Impl::up_f(m.tf_norm, Impl::tensor(g, "codec.tf.norm"));
+    {
+        const int half = m.head_dim / 2;
+        std::vector<float> c((size_t)m.max_pos * half), s((size_t)m.max_pos * half);
+        for (int p = 0; p < m.max_pos; p++) for (int i = 0; i < half; i++) {
+            const double ang = (double)p * std::pow((double)m.rope_base, -(double)i / half);
+            c[(size_t)p * half + i] = (float)std::cos(ang); s[(size_t)p * half + i] = (float)std::sin(ang);
+        }
+        Impl::up_f(m.rope_c, c); Impl::up_f(m.rope_s, s);
+    }
+    int rate = 1;
+    m.up.resize(m.n_up);
+    for (int i = 0; i < m.n_up; i++) {
+        auto& U = m.up[i];
+        const std::string p = "codec.up." + std::to_string(i) + ".";
+        const int f = m.up_ratios[i];
+        m.make_convt(U.ct, g, p + "convt.weight", p + "convt.bias", H, H, f, f);
+        Impl::up_f(U.dw_w, Impl::tensor(g, p + "dw.weight")); Impl::up_f(U.dw_b, Impl::tensor(g, p + "dw.bias"));
+        Impl::up_f(U.ln_w, Impl::tensor(g, p + "ln.weight")); Impl::up_f(U.ln_b, Impl::tensor(g, p + "ln.bias"));
+        m.make_linear(U.pw1, Impl::tensor(g, p + "pw1.weight"), 4 * H, H); Impl::up_f(U.pw1.b, Impl::tensor(g, p + "pw1.bias"));
+        m.make_linear(U.pw2, Impl::tensor(g, p + "pw2.weight"), H, 4 * H); Impl::up_f(U.pw2.b, Impl::tensor(g, p + "pw2.bias"));
+        Impl::up_f(U.gamma, Impl::tensor(g, p + "gamma"));
+        fl += rate * 2.0 * H * H * f;
+        rate *= f;
+        fl += rate * 2.0 * (7.0 * H + 8.0 * H * H);
+    }
+    m.make_conv(m.conv_in, g, "codec.dec.conv_in.weight", "codec.dec.conv_in.bias", m.dec_dim, H, 7, 1);
+    fl += rate * 2.0 * 7.0 * H * m.dec_dim;
+    int ch = m.dec_dim;
+    m.blk.resize(m.n_dec);
+    for (int b = 0; b < m.n_dec; b++) {
+        auto& B = m.blk[b];
+        const std::string p = "codec.dec." + std::to_string(b) + ".";
+        const int r = m.dec_rates[b], co = ch / 2;
+        B.cin = ch; B.cout = co; B.rate = r;
+        m.make_snake(B.snake, g, p + "snake.alpha", p + "snake.beta", ch);
+        m.make_convt(B.ct, g, p + "convt.weight", p + "convt.bias", ch, co, 2 * r, r);
+        fl += rate * 2.0 * ch * co * 2.0 * r;
+        rate *= r;
+        static const int dil[3] = {1, 3, 9};
+        for (int u = 0; u < 3; u++) {
+            const std::string q = p + "ru." + std::to_string(u) + ".";
+            m.make_snake(B.ru[u].s1, g, q + "snake1.alpha", q + "snake1.beta", co);
+            m.make_conv(B.ru[u].c1, g, q + "conv1.weight", q + "conv1.bias", co, co, 7, dil[u]);
+            m.make_snake(B.ru[u].s2, g, q + "snake2.alpha", q + "snake2.beta", co);
+            m.make_conv(B.ru[u].c2, g, q + "conv2.weight", q + "conv2.bias", co, co, 1, 1);
+            fl += rate * 2.0 * co * co * 8.0;
+        }
+        ch = co;
+    }
+    m.make_snake(m.snake_out, g, "codec.dec.snake_out.alpha", "codec.dec.snake_out.beta", ch);
+    {   // conv_out weight [1][ch][7] -> [j][c]
+        auto w = Impl::tensor(g, "codec.dec.conv_out.weight");
+        std::vector<float> r((size_t)7 * ch);
+        for (int c = 0; c < ch; c++) for (int j = 0; j < 7; j++) r[(size_t)j * ch + c] = w[(size_t)c * 7 + j];
+        Impl::up_f(m.conv_out_w, r);
+        m.conv_out_b = Impl::tensor(g, "codec.dec.conv_out.bias")[0];
+        fl += rate * 2.0 * 7.0 * ch;
+    }
+    m.flops_frame = fl;
+    // ---- per-stream state + scratch ----
+    const int T0 = max_frames;
+    m.make_ext(m.z_ext, 2, m.cb_dim, T0);
+    int T = T0;
+    m.dw_ext.resize(m.n_up);
+    for (int i = 0; i < m.n_up; i++) { T *= m.up_ratios[i]; m.make_ext(m.dw_ext[i], 6, H, T); }
+    const int Tlat = T;
+    m.make_ext(m.convin_ext, 6, H, Tlat);
+    m.ct_ext.resize(m.n_dec); m.ru_ext.resize(m.n_dec);
+    size_t max_act = (size_t)Tlat * 4 * H, max_hist = (size_t)6 * H;
+    ch = m.dec_dim;
+    static const int dil[3] = {1, 3, 9};
+    for (int b = 0; b < m.n_dec; b++) {
+        m.make_ext(m.ct_ext[b], 1, ch, T);
+        T *= m.dec_rates[b]; ch /= 2;
+        m.ru_ext[b].resize(3);
+        for (int u = 0; u < 3; u++) { m.make_ext(m.ru_ext[b][u], 6 * dil[u], ch, T); max_hist = std::max(max_hist, (size_t)6 * dil[u] * ch); }
+        max_act = std::max(max_act, (size_t)T * ch);
+    }
+    m.make_ext(m.out_ext, 6, ch, T);
+    max_act = std::max(max_act, (size_t)Tlat * m.dec_dim);
+    m.kbuf.resize(n_streams); m.vbuf.resize(n_streams);
+    for (int s = 0; s < n_streams; s++) {
+        m.kbuf[s].resize(m.n_layers); m.vbuf[s].resize(m.n_layers);
+        for (int l = 0; l < m.n_layers; l++) { m.kbuf[s][l].alloc((size_t)(m.window + T0) * H); m.vbuf[s][l].alloc((size_t)(m.window + T0) * H); m.kbuf[s][l].zero(); m.vbuf[s][l].zero(); }
+    }
+    m.kv_len.assign(n_streams, 0); m.n_seen.assign(n_streams, 0);
+    m.h.alloc((size_t)T0 * H); m.xn.alloc((size_t)T0 * H); m.qkv.alloc((size_t)T0 * 3 * H); m.att.alloc((size_t)T0 * H);
+    m.gu.alloc((size_t)T0 * 2 * m.ffn); m.act.alloc((size_t)T0 * m.ffn);
+    m.t1.alloc(max_act); m.t2.alloc(max_act); m.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); m.pcm.alloc((size_t)T);
+    m.d_codes.alloc((size_t)T0 * m.n_q);
+    Q3_HIP(hipDeviceSynchronize());
+}
+CodecDecoder::~CodecDecoder() {}
+int CodecDecoder::samples_per_frame() const {
+    int s = 1;
+    for (int i = 0; i < impl_->n_up; i++) s *= impl_->up_ratios[i];
+    for (int i = 0; i < impl_->n_dec; i++) s *= impl_->dec_rates[i];
+    return s;
+}
+double CodecDecoder::flops_per_frame() const { return impl_->flops_frame; }
+
+void CodecDecoder::reset(int s) {
+    Impl& m = *impl_;
+    Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
+    auto z = [&](Ext& e) { Q3_HIP(hipMemset(e.base(s), 0, (size_t)e.H * e.C * 4)); };
+    z(m.z_ext); z(m.convin_ext); z(m.out_ext);
+    for (auto& e : m.dw_ext) z(e);
+    for (auto& e : m.ct_ext) z(e);
+    for (auto& v : m.ru_ext) for (auto& e : v) z(e);
+    m.kv_len[s] = 0; m.n_seen[s] = 0;
+}
+
+int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
+    (void)is_last; // causal stack: nothing is held back (valid_samples == everything)
+    Impl& m = *impl_;
+    Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
+    if (n_frames <= 0) return 0;
+    Q3_CHECK(n_frames <= m.max_frames, "too many frames per decode call");
+    const int H = m.hidden, T0 = n_frames;
+    Q3_HIP(hipMemcpyAsync(m.d_codes.p, codes, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
+    // 1. RVQ sum -> z_ext current rows ; 2. pre_conv
+    hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, T0), dim3(256), 0, st, m.d_codes.p, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
+                       m.z_ext.cur(s), m.cb_dim);
+    m.run_conv(st, m.pre_conv, m.z_ext.base(s), m.cb_dim, T0, m.h.p, H);
+    m.shift(st, m.z_ext, s, T0);
+    // 3. transformer
+    const int kvl = m.kv_len[s];
+    for (int l = 0; l < m.n_layers; l++) {
+        auto& L = m.tf[l];
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, L.attn_norm.p, H, m.eps, m.xn.p, H);
+        m.run_conv(st, L.wqkv, m.xn.p, H, T0, m.qkv.p, 3 * H);
+        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, T0), dim3(256), 0, st, m.qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
+                           m.n_seen[s], m.max_pos);
+        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, T0), dim3(256), 0, st, m.qkv.p, 3 * H, H, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl);
+        hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, T0), dim3(64), 0, st, m.qkv.p, 3 * H, H, m.head_dim, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl,
+                           m.window, m.att.p, H);
+        m.run_conv(st, L.wo, m.att.p, H, T0, m.h.p, H, EPI_RES_SCALE, m.h.p, H, L.ls_attn.p);
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, L.ffn_norm.p, H, m.eps, m.xn.p, H);
+        m.run_conv(st, L.wgu, m.xn.p, H, T0, m.gu.p, 2 * m.ffn);
+        hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, T0), dim3(256), 0, st, m.gu.p, m.ffn, m.act.p);
+        m.run_conv(st, L.wdown, m.act.p, m.ffn, T0, m.h.p, H, EPI_RES_SCALE, m.h.p, H, L.ls_ffn.p);
+        // keep the last window-1 positions as history
+        const int tot = kvl + T0, keep = tot < m.window - 1 ? tot : m.window - 1;
+        if (tot > keep) {
+            const size_t n = (size_t)keep * H;
+            for (DevBuf<float>* b : {&m.kbuf[s][l], &m.vbuf[s][l]}) {
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->p + (size_t)(tot - keep) * H, m.tmp_hist.p, n);
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.tmp_hist.p, b->p, n);
+            }
+        }
+    }
+    {
+        const int tot = kvl + T0;
+        m.kv_len[s] = tot < m.window - 1 ? tot : m.window - 1;
+        m.n_seen[s] += T0;
+    }
+    // 4. final norm -> t1 [T0][H]
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, m.tf_norm.p, H, m.eps, m.t1.p, H);
+    // 5. upsample stages: x in t1
+    int T = T0;
+    float* x = m.t1.p;
+    for (int i = 0; i < m.n_up; i++) {
+        auto& U = m.up[i];
+        const int f = m.up_ratios[i];
+        Ext& e = m.dw_ext[i];
+        m.run_conv(st, U.ct, x, H, T, e.cur(s), f * H); // [T][f*H] == [T*f][H]
+        T *= f;
+        hipLaunchKernelGGL(k_dwconv7, dim3((H + 255) / 256, T), dim3(256), 0, st, e.base(s), H, U.dw_w.p, U.dw_b.p, m.t2.p);
+        hipLaunchKernelGGL(k_layernorm_rows, dim3(T), dim3(256), 0, st, m.t2.p, H, U.ln_w.p, U.ln_b.p, H, 1e-6f, m.t2.p, H);
+        float* m1 = m.t1.p; // [T][4H]
+        m.run_conv(st, U.pw1, m.t2.p, H, T, m1, 4 * H, EPI_GELU);
+        // y_new = y + gamma * (pw2(m1) + b): write into t2 (y lives in the ext buffer)
+        m.run_conv(st, U.pw2, m1, 4 * H, T, m.t2.p, H, EPI_RES_SCALE, e.cur(s), H, U.gamma.p);
+        m.shift(st, e, s, T);
+        // next stage input must not alias its own output buffers: move to t1
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, m.t2.p, m.t1.p, (size_t)T * H);
+        x = m.t1.p;
+    }
+    // 6. conv_in
+    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, x, m.convin_ext.cur(s), (size_t)T * H);
+    m.run_conv(st, m.conv_in, m.convin_ext.base(s), H, T, m.t1.p, m.dec_dim);
+    m.shift(st, m.convin_ext, s, T);
+    float* d = m.t1.p; // [T][ch]
+    // 7. decoder blocks
+    for (int b = 0; b < m.n_dec; b++) {
+        auto& B = m.blk[b];
+        Ext& ce = m.ct_ext[b];
+        m.snake(st, B.snake, d, ce.cur(s), T);
+        float* y = (d == m.t1.p) ? m.t2.p : m.t1.p; // [T*r][co]
+        m.run_conv(st, B.ct, ce.base(s), B.cin, T, y, B.rate * B.cout);
+        m.shift(st, ce, s, T);
+        T *= B.rate;
+        for (int u = 0; u < 3; u++) {
+            Ext& re = m.ru_ext[b][u];
+            auto& R = B.ru[u];
+            m.snake(st, R.s1, y, re.cur(s), T);
+            float* c1o = d; // the block input buffer is free now: reuse as scratch [T][co]
+            m.run_conv(st, R.c1, re.base(s), B.cout, T, c1o, B.cout);
+            m.shift(st, re, s, T);
+            m.snake(st, R.s2, c1o, c1o, T);
+            m.run_conv(st, R.c2, c1o, B.cout, T, y, B.cout, EPI_RES, y, B.cout);
+        }
+        d = y;
+    }
+    // 8. output conv
+    m.snake(st, m.snake_out, d, m.out_ext.cur(s), T);
+    hipLaunchKernelGGL(k_conv_out, dim3((T + 255) / 256), dim3(256), 0, st, m.out_ext.base(s), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.pcm.p, T);
+    m.shift(st, m.out_ext, s, T);
+    Q3_HIP(hipMemcpyAsync(pcm, m.pcm.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
+    Q3_HIP(hipStreamSynchronize(st));
+    return T;
+}
+
+} // namespace q3

@@ -2,6 +2,7 @@
 #include "engine.h"
 #include <algorithm>
 #include <chrono>
+#include "kdev.h"
 
 namespace q3 {
 
@@ -57,13 +58,13 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     // ---- per-sequence state ----
     hist_stride_ = p.max_steps * 16;
     tl_stride_ = (Q3_SAMPLE_END + 31) & ~31;
-    d_tseq_.alloc(B); d_tslot_.alloc(B); d_tpos_.alloc(4 * B); d_cur_.alloc(16 * B); d_nframes_.alloc(B); d_finished_.alloc(B);
+    d_tseq_.alloc(B); d_tslot_.alloc(B); d_tpos_.alloc(4 * B); d_keys_.alloc(16 * B); d_next_key0_.alloc(B); d_nframes_.alloc(B); d_finished_.alloc(B);
     d_maxframes_.alloc(B); d_maskeos_.alloc(B); d_hist_.alloc((size_t)B * hist_stride_);
     d_tlogits_.alloc((size_t)B * tl_stride_); d_thidden_.alloc((size_t)B * Q3_EMBD); d_pin_.alloc((size_t)2 * B * dP_);
     d_plogits_.alloc((size_t)B * Q3_CODEBOOK_SIZE); d_fb_.alloc((size_t)B * Q3_EMBD);
     d_prompt_.alloc((size_t)p.max_prompt * Q3_EMBD); d_hid_all_.alloc((size_t)talker_->max_tok() * Q3_EMBD);
     d_pf_seq_.alloc(talker_->max_tok()); d_pf_slot_.alloc(talker_->max_tok()); d_pf_pos_.alloc(4 * (size_t)talker_->max_tok());
-    d_cur_.zero(); d_hist_.zero(); d_tlogits_.zero(); d_thidden_.zero();
+    d_hist_.zero(); d_tlogits_.zero(); d_thidden_.zero();
     // predictor routing: pass i (i = 1..15) handles position i for every sequence; pass A = positions 0 and 1 (2B tokens)
     std::vector<int32_t> seq(B), slot((size_t)16 * B), pos((size_t)16 * B * 4), seqA(2 * B), slotA(2 * B), posA((size_t)2 * B * 4);
     for (int b = 0; b < B; b++) {
@@ -100,38 +101,44 @@ size_t Engine::bytes_per_frame_step(int batch, double mean_ctx) const {
            (size_t)((double)batch * mean_ctx * (double)kv_per_tok) + (size_t)batch * 17 * 8192;
 }
 
-// One frame for B lock-stepped sequences (engine.rs:545-641)
+// One frame for B lock-stepped sequences (engine.rs:545-641).  code_0 of the frame is already in keys[b][0]: it was
+// produced by the argmax epilogue of the talker head that ended the previous frame (or the prefill), or by the host sampler.
 void Engine::record_frame(int B) {
     const KvCache kvt = kv_t_->view(), kvp = kv_p_->view();
-    if (!code0_given_) // :550-555 talker sample over [0,2160) (greedy branch llama/mod.rs:690-701)
-        launch_argmax(st_, d_tlogits_.p, tl_stride_, 0, Q3_SAMPLE_END, d_maskeos_.p, d_cur_.p, 16, 0, B);
     // :565-573 predictor input = [project(m_hidden) ; project(E_0[code_0])]
-    launch_project(st_, d_thidden_.p, Q3_EMBD, d_proj_wt_.p, d_proj_b_.p, Q3_EMBD, dP_, d_pin_.p, dP_, B);
-    launch_gather_rows(st_, d_proj_tab_[0].p, assets_->codec_rows[0], d_cur_.p, 16, dP_, d_pin_.p + (size_t)B * dP_, B);
-    {   // :575-582 clear KV (= positions restart at 0) + 2-token prefill
+    launch_project_fast(st_, d_thidden_.p, Q3_EMBD, d_proj_wt_.p, d_proj_b_.p, Q3_EMBD, dP_, d_pin_.p, dP_, B);
+    launch_gather_rows_keys(st_, d_proj_tab_[0].p, assets_->codec_rows[0], d_keys_.p, 16, dP_, d_pin_.p + (size_t)B * dP_, B);
+    {   // :575-582 clear KV (= positions restart at 0) + 2-token prefill; :588-596 only slice q-1 of the 30720 logits is needed
         TokMeta tm{d_pseqA_.p, d_pslotA_.p, d_pposA_.p};
         Transformer::Input in; in.x = d_pin_.p; in.x_stride = dP_;
+        predictor_->set_same_seq_tokens(true);
         predictor_->forward(st_, in, 2 * B, tm, kvp, nullptr);
-        predictor_->head(st_, B, B, 0, Q3_CODEBOOK_SIZE, d_plogits_.p, Q3_CODEBOOK_SIZE); // :588-596 slice (q-1)*2048..q*2048 only
-        launch_argmax(st_, d_plogits_.p, Q3_CODEBOOK_SIZE, 0, Q3_CODEBOOK_SIZE, nullptr, d_cur_.p + 1, 16, 0, B);
+        ArgmaxEpi am{d_keys_.p + 1, 16, nullptr, 0};
+        predictor_->head(st_, B, B, 0, Q3_CODEBOOK_SIZE, nullptr, 0, &am);
     }
+    predictor_->set_same_seq_tokens(false);
     for (int q = 1; q < 15; q++) { // :602-610 decode project(E_q[code_q]) at pos q+1
         TokMeta tm{d_pseq_.p, d_pslot_.p + (size_t)(q + 1) * B, d_ppos_.p + (size_t)(q + 1) * B * 4};
-        Transformer::Input in; in.x = d_proj_tab_[q].p; in.x_stride = dP_; in.idx = d_cur_.p + q; in.idx_stride = 16;
+        Transformer::Input in; in.x = d_proj_tab_[q].p; in.x_stride = dP_; in.idx_keys = d_keys_.p + q; in.idx_stride = 16;
         predictor_->forward(st_, in, B, tm, kvp, nullptr);
-        predictor_->head(st_, 0, B, q * Q3_CODEBOOK_SIZE, Q3_CODEBOOK_SIZE, d_plogits_.p, Q3_CODEBOOK_SIZE);
-        launch_argmax(st_, d_plogits_.p, Q3_CODEBOOK_SIZE, 0, Q3_CODEBOOK_SIZE, nullptr, d_cur_.p + q + 1, 16, 0, B);
+        ArgmaxEpi am{d_keys_.p + q + 1, 16, nullptr, 0};
+        predictor_->head(st_, 0, B, q * Q3_CODEBOOK_SIZE, Q3_CODEBOOK_SIZE, nullptr, 0, &am);
     }
-    // :622-631 feedback ; :633-639 talker step at pos = cur_pos
-    launch_feedback(st_, d_tab_ptrs_.p, d_tab_rows_.p, d_cur_.p, 16, d_tts_pad_.p, d_fb_.p, B);
+    // :622-631 feedback ; :633-639 talker step at pos = cur_pos ; :550-555 next frame's code_0 (greedy branch)
+    launch_feedback_keys(st_, d_tab_ptrs_.p, d_tab_rows_.p, d_keys_.p, 16, d_tts_pad_.p, d_fb_.p, B);
     {
         TokMeta tm{d_tseq_.p, d_tslot_.p, d_tpos_.p};
         Transformer::Input in; in.x = d_fb_.p; in.x_stride = Q3_EMBD;
-        talker_->forward(st_, in, B, tm, kvt, d_thidden_.p);
-        talker_->head(st_, 0, B, 0, tl_stride_, d_tlogits_.p, tl_stride_);
+        talker_->set_same_seq_tokens(false);
+        talker_->forward(st_, in, B, tm, kvt, nullptr);
+        if (code0_given_) talker_->head(st_, 0, B, 0, tl_stride_, d_tlogits_.p, tl_stride_, nullptr, -1, d_thidden_.p);
+        else {
+            ArgmaxEpi am{d_next_key0_.p, 1, d_maskeos_.p, 0};
+            talker_->head(st_, 0, B, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p);
+        }
     }
-    AdvanceArgs a{B, d_finished_.p, d_nframes_.p, d_maxframes_.p, d_cur_.p, d_hist_.p, hist_stride_, d_tslot_.p, d_tpos_.p};
-    launch_advance(st_, a);
+    AdvanceKeysArgs a{B, d_finished_.p, d_nframes_.p, d_maxframes_.p, d_keys_.p, d_next_key0_.p, d_hist_.p, hist_stride_, d_tslot_.p, d_tpos_.p};
+    launch_advance_keys(st_, a);
 }
 
 void Engine::build_graph(int B) {
@@ -158,6 +165,13 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
     hipEvent_t ev0, ev1;
     Q3_HIP(hipEventCreate(&ev0)); Q3_HIP(hipEventCreate(&ev1));
     Q3_HIP(hipEventRecord(ev0, st_));
+    bool any_sampled_req = false;
+    for (int b = 0; b < B; b++) { mask[b] = reqs[b].mask_eos ? Q3_CODEC_EOS : -1; if (reqs[b].sampler.temperature > 0.0f) any_sampled_req = true; }
+    d_maskeos_.upload(mask.data(), W);
+    {
+        std::vector<q3_u64> k0((size_t)16 * W, pack_key(-INFINITY, 0)), n0(W, pack_key(-INFINITY, 0));
+        d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
+    }
     // ---------------- prefill, one sequence at a time (engine.rs:455-462) ----------------
     for (int b = 0; b < B; b++) {
         const GenRequest& r = reqs[b];
@@ -177,19 +191,24 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
             Q3_HIP(hipStreamSynchronize(st_)); // host vectors go out of scope
             TokMeta tm{d_pf_seq_.p, d_pf_slot_.p, d_pf_pos_.p};
             Transformer::Input in; in.x = d_prompt_.p + (size_t)t0c * Q3_EMBD; in.x_stride = Q3_EMBD;
-            talker_->forward(st_, in, n, tm, kv_t_->view(), d_hid_all_.p);
-            if (t0c + n == r.n_prompt) { // logits + hidden of the LAST prompt token (engine.rs:550-554,565-566)
-                talker_->head(st_, n - 1, 1, 0, tl_stride_, d_tlogits_.p + (size_t)b * tl_stride_, tl_stride_);
-                launch_copy_f32(st_, d_hid_all_.p + (size_t)(n - 1) * Q3_EMBD, d_thidden_.p + (size_t)b * Q3_EMBD, Q3_EMBD);
+            talker_->set_same_seq_tokens(true);
+            talker_->forward(st_, in, n, tm, kv_t_->view(), nullptr);
+            if (t0c + n == r.n_prompt) { // logits / code_0 + hidden of the LAST prompt token (engine.rs:550-554,565-566)
+                if (r.sampler.temperature > 0.0f || any_sampled_req)
+                    talker_->head(st_, n - 1, 1, 0, tl_stride_, d_tlogits_.p + (size_t)b * tl_stride_, tl_stride_, nullptr, -1, d_thidden_.p + (size_t)b * Q3_EMBD);
+                else {
+                    ArgmaxEpi am{d_keys_.p + (size_t)b * 16, 16, d_maskeos_.p + b, 0};
+                    talker_->head(st_, n - 1, 1, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p + (size_t)b * Q3_EMBD);
+                }
             }
         }
-        maxf[b] = r.max_steps; mask[b] = r.mask_eos ? Q3_CODEC_EOS : -1; fin[b] = 0;
+        maxf[b] = r.max_steps; fin[b] = 0;
         tslot[b] = r.n_prompt; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = r.n_prompt;
         max_steps_all = std::max(max_steps_all, r.max_steps);
         if (r.sampler.temperature > 0.0f) any_sampled = true;
     }
     for (int b = B; b < W; b++) { tslot[b] = 0; } // idle slots write to their single reserved page
-    d_maxframes_.upload(maxf.data(), W); d_maskeos_.upload(mask.data(), W); d_finished_.upload(fin.data(), W);
+    d_maxframes_.upload(maxf.data(), W); d_finished_.upload(fin.data(), W);
     d_nframes_.upload(nfr.data(), W); d_tslot_.upload(tslot.data(), W); d_tpos_.upload(tpos.data(), (size_t)4 * W);
     Q3_HIP(hipEventRecord(ev1, st_));
     Q3_HIP(hipStreamSynchronize(st_));
@@ -237,17 +256,15 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
         const int group = any_sampled ? 1 : std::min(4, max_steps_all - step);
         Q3_HIP(hipEventRecord(ev0, st_));
         for (int g = 0; g < group; g++) {
-            if (any_sampled) { // host sampler on logits [0,2160) (llama/mod.rs:703-775)
+            if (any_sampled) { // host sampler on logits [0,2160) (llama/mod.rs:666-775; greedy requests take its T<=0 branch)
                 hlogits.resize((size_t)W * tl_stride_);
                 d_tlogits_.download(hlogits.data(), hlogits.size());
-                std::vector<int32_t> cur((size_t)16 * W);
-                d_cur_.download(cur.data(), cur.size());
                 for (int b = 0; b < B; b++) {
                     float* lg = hlogits.data() + (size_t)b * tl_stride_;
                     if (reqs[b].mask_eos) lg[Q3_CODEC_EOS] = -INFINITY;
-                    cur[(size_t)16 * b] = samplers[b].sample(lg, tl_stride_, 0, Q3_SAMPLE_END);
+                    const q3_u64 key = pack_key(0.0f, samplers[b].sample(lg, tl_stride_, 0, Q3_SAMPLE_END));
+                    Q3_HIP(hipMemcpy(d_keys_.p + (size_t)16 * b, &key, 8, hipMemcpyHostToDevice));
                 }
-                d_cur_.upload(cur.data(), cur.size());
             }
             if (eager) record_frame(W);
             else Q3_HIP(hipGraphLaunch(graph_exec_, st_));

@@ -73,7 +73,8 @@ private:
     int dP_ = 0;
     // per-sequence device state
     int B_ = 0;
-    DevBuf<int32_t> d_tseq_, d_tslot_, d_tpos_, d_cur_, d_nframes_, d_finished_, d_maxframes_, d_hist_, d_maskeos_;
+    DevBuf<int32_t> d_tseq_, d_tslot_, d_tpos_, d_nframes_, d_finished_, d_maxframes_, d_hist_, d_maskeos_;
+    DevBuf<q3_u64> d_keys_, d_next_key0_; // argmax keys: [B][16] codes of the current frame, [B] code_0 of the next frame
     DevBuf<int32_t> d_pseq_, d_pslot_, d_ppos_, d_pseqA_, d_pslotA_, d_pposA_;
     DevBuf<float> d_tlogits_, d_thidden_, d_pin_, d_plogits_, d_fb_, d_prompt_, d_hid_all_;
     DevBuf<int32_t> d_pf_seq_, d_pf_slot_, d_pf_pos_;

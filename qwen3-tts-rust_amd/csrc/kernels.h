@@ -91,4 +91,40 @@ void launch_advance(hipStream_t st, const AdvanceArgs& a);
 
 void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
 
+// ------------------------------- fused decode-step kernels (kernels_fused.hip) -------------------------------
+typedef unsigned long long q3_u64;
+// prologue of the fused GEMVs: h = h_in (+ parts); RMSNorm; quantise (spec S9,S4,S2)
+struct NormPro {
+    const float* h_in; int h_stride;
+    const q3_u64* idx_keys; int idx_stride;     // optional: row = h_in + code(idx_keys[tok*idx_stride]) * h_stride
+    const float* parts; int nparts; int parts_stride; size_t parts_slab; // slab p at parts + p*parts_slab, row tok at + tok*parts_stride
+    float* h_out;                               // optional [ntok][d]; MUST NOT alias h_in (other workgroups still read it)
+    const float* g; float eps;
+    float* xn_out;                              // optional [ntok][d]
+};
+// epilogue of the head GEMV: first-max argmax through one 64-bit atomicMax per workgroup and token
+struct ArgmaxEpi {
+    q3_u64* keys; int key_stride;               // keys[tok*key_stride], pre-armed with pack_key(-inf, 0)
+    const int32_t* mask_per_tok;                // optional: index excluded from the argmax (EOS masking)
+    int idx_add;                                // added to the row index (0: slice-relative codes)
+};
+void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride,
+                         int ntok, const ArgmaxEpi* am);
+void launch_gateup_swiglu(hipStream_t st, const Q8Mat& wgu, int ff, const NormPro& a, int8_t* aq, uint16_t* ad, int ntok);
+void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
+                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
+                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad,
+                            int ntok);
+void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
+                         float* out, int out_stride, int ntok);
+void launch_feedback_keys(hipStream_t st, const float* const* tables, const int64_t* table_rows, const q3_u64* keys, int key_stride,
+                          const float* tts_pad, float* out, int ntok);
+void launch_gather_rows_keys(hipStream_t st, const float* table, int64_t rows, const q3_u64* keys, int key_stride, int row_len,
+                             float* dst, int ntok);
+struct AdvanceKeysArgs {
+    int B; int32_t *finished, *n_frames; const int32_t* max_frames; q3_u64* keys; q3_u64* next_key0; int32_t* hist; int hist_stride;
+    int32_t *t_slot, *t_pos;
+};
+void launch_advance_keys(hipStream_t st, const AdvanceKeysArgs& a);
+
 } // namespace q3

@@ -9,32 +9,9 @@
 // before first use, wave-shuffle reductions, and >=256 workgroups per launch.  No MFMA here on purpose.
 #include "kernels.h"
 #include "../../include/q3tts_spec.h"
+#include "kdev.h"
 
 namespace q3 {
-
-__device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
-__device__ __forceinline__ float wave_sum_bfly(float v) { // spec butterfly: xor 32,16,8,4,2,1
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
-    return v;
-}
-__device__ __forceinline__ float wave_max_bfly(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
-    return v;
-}
-__device__ __forceinline__ int dot16(const uint4& a, const uint4& b) {
-    int s = __builtin_amdgcn_sdot4((int)a.x, (int)b.x, 0, false);
-    s = __builtin_amdgcn_sdot4((int)a.y, (int)b.y, s, false);
-    s = __builtin_amdgcn_sdot4((int)a.z, (int)b.z, s, false);
-    s = __builtin_amdgcn_sdot4((int)a.w, (int)b.w, s, false);
-    return s;
-}
-__device__ __forceinline__ uint32_t half_of(const uint4& v, int b) { // b-th f16 of 8 packed halfs (b constant)
-    uint32_t w = (b >> 1) == 0 ? v.x : (b >> 1) == 1 ? v.y : (b >> 1) == 2 ? v.z : v.w;
-    return (b & 1) ? (w >> 16) : (w & 0xFFFFu);
-}
 
 // =====================================================================================================
 // Q8_0 GEMV / skinny GEMM (spec S3).  One wave = R rows x one 256-element segment; LPR = 64/R lanes share

@@ -1,0 +1,520 @@
+// kernels_fused.hip -- fused decode-step kernels (5 launches per transformer layer instead of 9).
+//
+// Batch-1 decode on MI355X is bound by the number of dependent launches (measured: 1.7 us per trivial graph
+// node + 2-4 us of load->reduce->store latency per kernel, profiles/r01_*), not by HBM, so every
+// elementwise / normalisation / quantisation step is folded into the kernel that produces or consumes it:
+//   A  k_gemv_q8_norm     [residual + RMSNorm + int8 quant] prologue -> Q8_0 GEMV  (QKV; head with atomic argmax)
+//   B  k_attention_fused  per-head q/k RMSNorm + M-RoPE + KV append + paged GQA attention + int8 quant
+//   C  k_gemv_q8          o-proj (kernels.hip)
+//   D  k_gateup_swiglu    [residual + RMSNorm + quant] -> gate & up GEMV -> SwiGLU -> int8 quant
+//   E  k_gemv_q8          down-proj (kernels.hip)
+// Arithmetic is include/q3tts_spec.h's, bit-identical to the unfused kernels and to oracle/.
+#include "kernels.h"
+#include "kdev.h"
+
+namespace q3 {
+
+// ---------------------------------------------------------------------------------------------------
+// one wave: h = h_in (+ parts, in order); RMSNorm; quantise to LDS.  (same arithmetic as k_rmsnorm_quant)
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void norm_quant_token(const NormPro& a, int d, int tok, int ntok, int lane, int8_t* xq_dst,
+                                                 uint16_t* xd_dst, bool write_global) {
+    const int nch = d >> 8;
+    const float* hin = a.h_in;
+    if (a.idx_keys) hin += (size_t)key_code(a.idx_keys[(size_t)tok * a.idx_stride]) * a.h_stride;
+    else hin += (size_t)tok * a.h_stride;
+    float4 x[8];
+    float p = 0.0f;
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (c < nch) {
+            float4 v = *reinterpret_cast<const float4*>(hin + 256 * c + 4 * lane);
+            if (a.nparts > 0) {
+                const float* pp = a.parts + (size_t)tok * a.parts_stride + 256 * c + 4 * lane;
+                float4 y = *reinterpret_cast<const float4*>(pp);
+                for (int s = 1; s < a.nparts; s++) {
+                    const float4 z = *reinterpret_cast<const float4*>(pp + (size_t)s * a.parts_slab);
+                    y.x = y.x + z.x; y.y = y.y + z.y; y.z = y.z + z.z; y.w = y.w + z.w;
+                }
+                v.x = v.x + y.x; v.y = v.y + y.y; v.z = v.z + y.z; v.w = v.w + y.w;
+            }
+            if (write_global && a.h_out) *reinterpret_cast<float4*>(a.h_out + (size_t)tok * d + 256 * c + 4 * lane) = v;
+            x[c] = v;
+            p = q3_fmaf(v.x, v.x, p); p = q3_fmaf(v.y, v.y, p); p = q3_fmaf(v.z, v.z, p); p = q3_fmaf(v.w, v.w, p);
+        }
+    }
+    const float ss = wave_sum_bfly(p);
+    const float mean = ss / (float)d;
+    const float scale = 1.0f / q3_sqrtf(mean + a.eps);
+#pragma unroll
+    for (int c = 0; c < 8; c++) {
+        if (c < nch) {
+            const float4 g = *reinterpret_cast<const float4*>(a.g + 256 * c + 4 * lane);
+            float4 y;
+            y.x = (x[c].x * scale) * g.x; y.y = (x[c].y * scale) * g.y;
+            y.z = (x[c].z * scale) * g.z; y.w = (x[c].w * scale) * g.w;
+            if (write_global && a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * d + 256 * c + 4 * lane) = y;
+            float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
+            amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+            const float dd = amax / 127.0f;
+            const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+            const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
+            const uint32_t pk = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3v & 0xFF) << 24);
+            *reinterpret_cast<uint32_t*>(xq_dst + 256 * c + 4 * lane) = pk;
+            if ((lane & 7) == 0) xd_dst[8 * c + (lane >> 3)] = f2h(dd);
+        }
+    }
+}
+
+// ===================================================================================================
+// A: norm prologue + GEMV (K = d <= 2048, one super-segment).  EPI 0: store f32; EPI 1: atomic argmax.
+// ===================================================================================================
+template <int LPR, int MT, int EPI>
+__global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nrows, NormPro a, float* __restrict__ out,
+                                                      int out_stride, int ntok, ArgmaxEpi am) {
+    constexpr int R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    __shared__ float red[8][R * MT];
+    __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
+    __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int seg = wave; // single super-segment
+    const int tok0 = blockIdx.z * MT;
+    int row = row0 + blockIdx.x * R + r;
+    if (row > w.Npad - 1) row = w.Npad - 1;
+    const int rg = row >> 5, r32 = row & 31;
+    // weight stream first: independent of the activations, flies while the prologue runs
+    const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+    uint4 wv[NLD];
+#pragma unroll
+    for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
+    const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+    for (int m = wave; m < MT; m += nwaves) {
+        const int tok = tok0 + m;
+        if (tok < ntok) norm_quant_token(a, w.K, tok, ntok, lane, xq_s[m], xd_s[m], blockIdx.x == 0);
+    }
+    __syncthreads();
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        acc[m] = 0.0f;
+        const int mm = (tok0 + m < ntok) ? m : 0; // clamp like the unfused kernel (result unused)
+        const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
+#pragma unroll
+        for (int i = 0; i < NLD; i++) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + (i * BPL + bil) * 32 + half * 16]);
+            int isum = dot16(wv[i], xv);
+            isum += __shfl_xor(isum, R);
+#pragma unroll
+            for (int j = 0; j < BPL; j++) {
+                const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
+                const int b = i * BPL + j;
+                const float sc = h2f(half_of(dwv, b)) * h2f(half_of(dxv, b));
+                acc[m] = q3_fmaf((float)isj, sc, acc[m]);
+            }
+        }
+    }
+    if (q == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < R * MT) {
+        const int m = t / R, rr = t % R;
+        float S = red[0][t];
+        for (int s = 1; s < nseg; s++) S = S + red[s][t];
+        const int orow = blockIdx.x * R + rr, tok = tok0 + m;
+        const bool ok = orow < nrows && tok < ntok;
+        if (EPI == 0) {
+            if (ok) out[(size_t)tok * out_stride + orow] = S;
+        } else {
+            // first-max over this workgroup's R rows (R <= 32 lanes share a token), then one atomic per token
+            const int gi = orow + am.idx_add;
+            const int mk = (ok && am.mask_per_tok) ? am.mask_per_tok[tok] : -1;
+            u64 key = (ok && gi != mk && S > -INFINITY) ? pack_key(S, gi) : 0ull;
+#pragma unroll
+            for (int sft = R / 2; sft >= 1; sft >>= 1) {
+                const u64 o = __shfl_xor(key, sft);
+                key = o > key ? o : key;
+            }
+            if (rr == 0 && key != 0ull && tok < ntok) atomicMax(am.keys + (size_t)tok * am.key_stride, key);
+        }
+    }
+}
+
+template <int LPR, int MT, int EPI>
+static void gemv_norm_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride,
+                             int ntok, const ArgmaxEpi& am) {
+    constexpr int R = 64 / LPR;
+    const int nseg = w.K >> 8;
+    dim3 grid((nrows + R - 1) / R, 1, (ntok + MT - 1) / MT);
+    hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
+}
+template <int LPR, int EPI>
+static void gemv_norm_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride, int ntok,
+                         const ArgmaxEpi& am) {
+    if (ntok == 1) gemv_norm_launch<LPR, 1, EPI>(st, w, row0, nrows, a, out, out_stride, ntok, am);
+    else if (ntok == 2) gemv_norm_launch<LPR, 2, EPI>(st, w, row0, nrows, a, out, out_stride, ntok, am);
+    else if (ntok <= 4) gemv_norm_launch<LPR, 4, EPI>(st, w, row0, nrows, a, out, out_stride, ntok, am);
+    else gemv_norm_launch<LPR, 8, EPI>(st, w, row0, nrows, a, out, out_stride, ntok, am);
+}
+void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride, int ntok,
+                         const ArgmaxEpi* am) {
+    ArgmaxEpi none{};
+    if (am) { gemv_norm_mt<2, 1>(st, w, row0, nrows, a, out, out_stride, ntok, *am); return; }
+    if (nrows / 32 >= 512) gemv_norm_mt<2, 0>(st, w, row0, nrows, a, out, out_stride, ntok, none);
+    else if (nrows / 16 >= 256) gemv_norm_mt<4, 0>(st, w, row0, nrows, a, out, out_stride, ntok, none);
+    else gemv_norm_mt<8, 0>(st, w, row0, nrows, a, out, out_stride, ntok, none);
+}
+
+// ===================================================================================================
+// D: norm prologue + gate & up GEMV + SwiGLU + int8 quant.  Workgroup = 32 gate rows + the 32 matching up
+// rows (one output quant block); wave = one segment of both (16 weight loads in flight per lane).
+// ===================================================================================================
+template <int MT>
+__global__ void __launch_bounds__(512) k_gateup_swiglu(Q8Mat w, int ff, NormPro a, int8_t* __restrict__ aq,
+                                                       uint16_t* __restrict__ ad, int ntok) {
+    __shared__ float red[8][2][32 * MT];
+    __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
+    __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int seg = wave;
+    const int tok0 = blockIdx.z * MT;
+    const int rgG = blockIdx.x, rgU = (ff >> 5) + blockIdx.x;
+    const uint8_t* baseG = w.qs + ((size_t)rgG * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
+    const uint8_t* baseU = w.qs + ((size_t)rgU * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
+    uint4 wg[8], wu[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) { wg[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wu[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
+    const uint4 dg = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
+    const uint4 du = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
+    for (int m = wave; m < MT; m += nwaves) {
+        const int tok = tok0 + m;
+        if (tok < ntok) norm_quant_token(a, w.K, tok, ntok, lane, xq_s[m], xd_s[m], blockIdx.x == 0);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        const int mm = (tok0 + m < ntok) ? m : 0;
+        const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
+        float ag = 0.0f, au = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
+            int ig = dot16(wg[i], xv), iu = dot16(wu[i], xv);
+            ig += __shfl_xor(ig, 32); iu += __shfl_xor(iu, 32);
+            const float dx = h2f(half_of(dxv, i));
+            ag = q3_fmaf((float)ig, h2f(half_of(dg, i)) * dx, ag);
+            au = q3_fmaf((float)iu, h2f(half_of(du, i)) * dx, au);
+        }
+        if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
+    }
+    __syncthreads();
+    const int t = threadIdx.x;
+    if (t < 32 * MT) {
+        const int m = t >> 5, rr = t & 31, tok = tok0 + m;
+        float G = red[0][0][t], U = red[0][1][t];
+        for (int s = 1; s < nseg; s++) { G = G + red[s][0][t]; U = U + red[s][1][t]; }
+        const float y = q3_swiglu(G, U);
+        float amax = q3_fabsf(y);
+#pragma unroll
+        for (int sft = 16; sft >= 1; sft >>= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+        const float dd = amax / 127.0f;
+        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+        if (tok < ntok) {
+            aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
+            if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+        }
+    }
+}
+void launch_gateup_swiglu(hipStream_t st, const Q8Mat& w, int ff, const NormPro& a, int8_t* aq, uint16_t* ad, int ntok) {
+    const int nseg = w.K >> 8;
+    const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : 4;
+    dim3 grid(ff / 32, 1, (ntok + mt - 1) / mt);
+    if (mt == 1) hipLaunchKernelGGL((k_gateup_swiglu<1>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
+    else if (mt == 2) hipLaunchKernelGGL((k_gateup_swiglu<2>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
+    else hipLaunchKernelGGL((k_gateup_swiglu<4>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
+}
+
+// ===================================================================================================
+// B: fused per-head norm + RoPE + KV append + attention for DECODE steps (every token of the launch belongs
+// to a different sequence, so no token needs another token's K/V from the same launch).  The current
+// position's K/V are taken from LDS (not re-read from global) so no intra-launch global visibility is needed.
+// ===================================================================================================
+__global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict__ qkv, int qkv_stride, int n_head, int n_kv,
+                                                         const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w,
+                                                         float eps, const float* __restrict__ rope_cos,
+                                                         const float* __restrict__ rope_sin, int n_ctx,
+                                                         const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv, int layer,
+                                                         int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+    __shared__ __attribute__((aligned(16))) float q_s[128];
+    __shared__ __attribute__((aligned(16))) uint16_t kcur_s[128];
+    __shared__ __attribute__((aligned(16))) uint16_t vcur_s[128];
+    __shared__ float p_s[256];
+    __shared__ float red_s[4][128];
+    __shared__ float wmax_s[4];
+    const int h = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int seq = tm.seq[tok], slot = tm.slot[tok], n = slot + 1;
+    const int grp = n_head / n_kv, kvh = h / grp;
+    const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
+    const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
+    // ---- prologue: wave 0 = q head, wave 1 = k head, wave 2 = v head ----
+    if (wave < 3) {
+        const float* vec = qkv + (size_t)tok * qkv_stride + (wave == 0 ? (size_t)h * 128 : wave == 1 ? (size_t)(n_head + kvh) * 128 : (size_t)(n_head + n_kv + kvh) * 128);
+        const float x1 = vec[lane], x2 = vec[lane + 64];
+        const int page = pt[slot >> 6], ps = slot & 63;
+        if (wave < 2) {
+            const float* wn = wave == 0 ? q_norm_w : k_norm_w;
+            float p = x1 * x1;
+            p = q3_fmaf(x2, x2, p);
+            const float ss = wave_sum_bfly(p);
+            const float mean = ss / 128.0f;
+            const float scale = 1.0f / q3_sqrtf(mean + eps);
+            const float y1 = (x1 * scale) * wn[lane], y2 = (x2 * scale) * wn[lane + 64];
+            int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
+            int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+            if (pp < 0) pp = 0;
+            if (pp > n_ctx - 1) pp = n_ctx - 1;
+            float o1, o2;
+            q3_rope_pair(y1, y2, rope_cos[(size_t)pp * 64 + lane], rope_sin[(size_t)pp * 64 + lane], &o1, &o2);
+            if (wave == 0) { q_s[lane] = o1; q_s[lane + 64] = o2; }
+            else {
+                const uint16_t k1 = f2h(o1), k2 = f2h(o2);
+                kcur_s[lane] = k1; kcur_s[lane + 64] = k2;
+                if (h % grp == 0) { // one writer per kv head
+                    uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+                    Kb[((lane >> 3) * 64 + ps) * 8 + (lane & 7)] = k1;
+                    Kb[(((lane + 64) >> 3) * 64 + ps) * 8 + (lane & 7)] = k2;
+                }
+            }
+        } else {
+            const uint16_t v1 = f2h(x1), v2 = f2h(x2);
+            vcur_s[lane] = v1; vcur_s[lane + 64] = v2;
+            if (h % grp == 0) {
+                uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
+                Vb[ps * 128 + lane] = v1; Vb[ps * 128 + lane + 64] = v2;
+            }
+        }
+    }
+    __syncthreads();
+    const float scale = 0.08838834764831845f;
+    const int jj = lane >> 4, dc = lane & 15;
+    float M = 0.0f, L = 0.0f, O[8];
+#pragma unroll
+    for (int i = 0; i < 8; i++) O[i] = 0.0f;
+    for (int c0 = 0; c0 < n; c0 += 256) {
+        const int jbase = c0 + wave * 64;
+        const int jme = jbase + lane;
+        const bool valid = jme < n;
+        float s = -INFINITY;
+        if (jbase < n) {
+            const int page = pt[jbase >> 6];
+            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+            const bool cur = (jme == slot);
+            float acc = 0.0f;
+#pragma unroll
+            for (int d8 = 0; d8 < 16; d8++) {
+                uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+                if (cur) kk = *reinterpret_cast<const uint4*>(&kcur_s[8 * d8]);
+                const float4 qa = *reinterpret_cast<const float4*>(&q_s[8 * d8]);
+                const float4 qb = *reinterpret_cast<const float4*>(&q_s[8 * d8 + 4]);
+                acc = q3_fmaf(qa.x, h2f(kk.x & 0xFFFFu), acc); acc = q3_fmaf(qa.y, h2f(kk.x >> 16), acc);
+                acc = q3_fmaf(qa.z, h2f(kk.y & 0xFFFFu), acc); acc = q3_fmaf(qa.w, h2f(kk.y >> 16), acc);
+                acc = q3_fmaf(qb.x, h2f(kk.z & 0xFFFFu), acc); acc = q3_fmaf(qb.y, h2f(kk.z >> 16), acc);
+                acc = q3_fmaf(qb.z, h2f(kk.w & 0xFFFFu), acc); acc = q3_fmaf(qb.w, h2f(kk.w >> 16), acc);
+            }
+            if (valid) s = acc * scale;
+        }
+        const float wm = wave_max_bfly(s);
+        if (lane == 0) wmax_s[wave] = wm;
+        __syncthreads();
+        const float mc = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
+        const float p = valid ? q3_expf(s - mc) : 0.0f;
+        p_s[wave * 64 + lane] = p;
+        __syncthreads();
+        float S[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) S[i] = 0.0f;
+        const int cn = (n - c0) < 256 ? (n - c0) : 256;
+#pragma unroll 4
+        for (int u = 0; u < 16; u++) {
+            if (16 * u < cn) {
+                const int jl = 16 * u + 4 * wave + jj;
+                const int jg = c0 + jl;
+                const float pj = p_s[jl];
+                uint4 vv = make_uint4(0, 0, 0, 0);
+                if (jg < n) {
+                    if (jg == slot) vv = *reinterpret_cast<const uint4*>(&vcur_s[dc * 8]);
+                    else {
+                        const int page = pt[jg >> 6];
+                        vv = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
+                    }
+                }
+                S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
+                S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
+                S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
+                S[6] = q3_fmaf(pj, h2f(vv.w & 0xFFFFu), S[6]); S[7] = q3_fmaf(pj, h2f(vv.w >> 16), S[7]);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            const float a2 = S[i] + __shfl_xor(S[i], 16);
+            const float T = a2 + __shfl_xor(a2, 32);
+            if (jj == 0) red_s[wave][dc * 8 + i] = T;
+        }
+        __syncthreads();
+        if (wave == 0) {
+            float a2 = p_s[lane];
+            a2 = a2 + p_s[lane + 64]; a2 = a2 + p_s[lane + 128]; a2 = a2 + p_s[lane + 192];
+            const float lc = wave_sum_bfly(a2);
+            float oc[8];
+#pragma unroll
+            for (int i = 0; i < 8; i++) oc[i] = (red_s[0][dc * 8 + i] + red_s[1][dc * 8 + i]) + (red_s[2][dc * 8 + i] + red_s[3][dc * 8 + i]);
+            if (c0 == 0) {
+                M = mc; L = lc;
+#pragma unroll
+                for (int i = 0; i < 8; i++) O[i] = oc[i];
+            } else {
+                const float mn = fmaxf(M, mc);
+                const float ea = q3_expf(M - mn), eb = q3_expf(mc - mn);
+                const float t2 = lc * eb;
+                L = q3_fmaf(L, ea, t2);
+#pragma unroll
+                for (int i = 0; i < 8; i++) { const float u2 = oc[i] * eb; O[i] = q3_fmaf(O[i], ea, u2); }
+                M = mn;
+            }
+        }
+        __syncthreads();
+    }
+    if (wave == 0) {
+        float y[8];
+        float amax = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { y[i] = O[i] / L; amax = fmaxf(amax, q3_fabsf(y[i])); }
+        amax = fmaxf(amax, __shfl_xor(amax, 1));
+        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        const float dd = amax / 127.0f;
+        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+        if (jj == 0) {
+            const size_t o = ((size_t)tok * n_head + h) * 128 + dc * 8;
+            uint32_t lo = 0, hi = 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) {
+                lo |= (uint32_t)((int)q3_rintf(y[i] * id) & 0xFF) << (8 * i);
+                hi |= (uint32_t)((int)q3_rintf(y[i + 4] * id) & 0xFF) << (8 * i);
+            }
+            *reinterpret_cast<uint2*>(aq + o) = make_uint2(lo, hi);
+            if ((dc & 3) == 0) ad[o >> 5] = f2h(dd);
+        }
+    }
+}
+void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
+                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
+                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad,
+                            int ntok) {
+    hipLaunchKernelGGL(k_attention_fused, dim3(n_head, ntok), dim3(256), 0, st, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w,
+                       eps, rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad);
+}
+
+// ===================================================================================================
+// projection with deep prefetch: one thread per output, 32 weight loads in flight per lane, sequential chain
+// (assets_manager.rs:383-399 order preserved exactly)
+// ===================================================================================================
+__global__ void __launch_bounds__(64) k_project_fast(const float* __restrict__ x, int x_stride, const float* __restrict__ Wt,
+                                                     const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
+                                                     int out_stride) {
+    extern __shared__ float xs[];
+    const int tok = blockIdx.y, o = blockIdx.x * 64 + threadIdx.x;
+    for (int i = threadIdx.x; i < n_in; i += 64) xs[i] = x[(size_t)tok * x_stride + i];
+    __syncthreads();
+    const int oo = o < n_out ? o : n_out - 1;
+    float sum = b[oo];
+    const float* wp = Wt + oo;
+    float wbuf[32];
+#pragma unroll
+    for (int j = 0; j < 32; j++) wbuf[j] = wp[(size_t)j * n_out];
+    for (int i0 = 0; i0 < n_in; i0 += 32) {
+        float wn[32];
+        const bool more = i0 + 32 < n_in;
+#pragma unroll
+        for (int j = 0; j < 32; j++) wn[j] = more ? wp[(size_t)(i0 + 32 + j) * n_out] : 0.0f;
+#pragma unroll
+        for (int j = 0; j < 32; j++) { const float t = xs[i0 + j] * wbuf[j]; sum = sum + t; }
+#pragma unroll
+        for (int j = 0; j < 32; j++) wbuf[j] = wn[j];
+    }
+    if (o < n_out) out[(size_t)tok * out_stride + o] = sum;
+}
+void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
+                         float* out, int out_stride, int ntok) {
+    hipLaunchKernelGGL(k_project_fast, dim3((n_out + 63) / 64, ntok), dim3(64), n_in * sizeof(float), st, x, x_stride, Wt, b, n_in,
+                       n_out, out, out_stride);
+}
+
+// ===================================================================================================
+// code consumers working on argmax keys
+// ===================================================================================================
+__global__ void __launch_bounds__(256) k_feedback_keys(const float* const* __restrict__ tables, const int64_t* __restrict__ table_rows,
+                                                       const u64* __restrict__ keys, int key_stride,
+                                                       const float* __restrict__ tts_pad, float* __restrict__ out) {
+    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    float acc = 0.0f;
+#pragma unroll
+    for (int q = 0; q < 16; q++) {
+        int c = key_code(keys[(size_t)tok * key_stride + q]);
+        if (c < 0) c = 0;
+        const float v = ((int64_t)c < table_rows[q]) ? tables[q][(size_t)c * 2048 + i] : 0.0f;
+        acc = acc + v;
+    }
+    acc = acc + tts_pad[i];
+    out[(size_t)tok * 2048 + i] = acc;
+}
+void launch_feedback_keys(hipStream_t st, const float* const* tables, const int64_t* table_rows, const u64* keys, int key_stride,
+                          const float* tts_pad, float* out, int ntok) {
+    hipLaunchKernelGGL(k_feedback_keys, dim3(8, ntok), dim3(256), 0, st, tables, table_rows, keys, key_stride, tts_pad, out);
+}
+
+// project(m_hidden) and the pre-projected E_0[code_0] row side by side: predictor pass-A input rows [0,B) and [B,2B)
+__global__ void __launch_bounds__(256) k_gather_rows_keys(const float* __restrict__ table, int64_t rows, const u64* __restrict__ keys,
+                                                          int key_stride, int row_len, float* __restrict__ dst) {
+    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= row_len) return;
+    int c = key_code(keys[(size_t)tok * key_stride]);
+    if (c < 0) c = 0;
+    dst[(size_t)tok * row_len + i] = ((int64_t)c < rows) ? table[(size_t)c * row_len + i] : 0.0f;
+}
+void launch_gather_rows_keys(hipStream_t st, const float* table, int64_t rows, const u64* keys, int key_stride, int row_len,
+                             float* dst, int ntok) {
+    hipLaunchKernelGGL(k_gather_rows_keys, dim3((row_len + 255) / 256, ntok), dim3(256), 0, st, table, rows, keys, key_stride, row_len, dst);
+}
+
+__global__ void k_advance_keys(AdvanceKeysArgs a) {
+    const int b = blockIdx.x * 64 + threadIdx.x;
+    if (b >= a.B) return;
+    u64* k = a.keys + (size_t)b * 16;
+    const bool live = !a.finished[b] && a.n_frames[b] < a.max_frames[b];
+    if (live) {
+        const int c0 = key_code(k[0]);
+        if (c0 == Q3_CODEC_EOS || c0 == Q3_TEXT_EOS) a.finished[b] = 1; // engine.rs:558-561
+        else {
+            int32_t* dst = a.hist + (size_t)b * a.hist_stride + (size_t)a.n_frames[b] * 16;
+            for (int q = 0; q < 16; q++) dst[q] = key_code(k[q]);
+            a.n_frames[b] = a.n_frames[b] + 1;
+            a.t_slot[b] = a.t_slot[b] + 1;
+            a.t_pos[b * 4 + 0] += 1; a.t_pos[b * 4 + 1] += 1; a.t_pos[b * 4 + 2] += 1;
+        }
+    }
+    // hand the next frame its code_0 (argmax of the talker logits just produced) and re-arm every key
+    k[0] = a.next_key0[b];
+    a.next_key0[b] = pack_key(-INFINITY, 0);
+    for (int q = 1; q < 16; q++) k[q] = pack_key(-INFINITY, 0);
+}
+void launch_advance_keys(hipStream_t st, const AdvanceKeysArgs& a) {
+    hipLaunchKernelGGL(k_advance_keys, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
+}
+
+} // namespace q3

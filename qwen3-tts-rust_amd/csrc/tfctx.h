@@ -34,19 +34,20 @@ public:
             d_seq_.upload(seq.data(), n); d_slot_.upload(slot.data(), n); d_pos_.upload(pos4 + (size_t)4 * t0, (size_t)4 * n);
             TokMeta tm{d_seq_.p, d_slot_.p, d_pos_.p};
             Transformer::Input in; in.x = d_x_.p; in.x_stride = hp.n_embd;
-            model_->forward(st_, in, n, tm, kv_->view(), d_hid_.p);
-            if (logits_out && row1 > row0) {
-                const int r0 = row0 & ~31, nr = row1 - r0;
-                if (d_logits_.n < (size_t)n * nr) d_logits_.alloc((size_t)n * nr);
-                model_->head(st_, 0, n, r0, nr, d_logits_.p, nr);
-                Q3_HIP(hipStreamSynchronize(st_));
+            model_->set_same_seq_tokens(true);
+            model_->forward(st_, in, n, tm, kv_->view(), model_->fused ? nullptr : d_hid_.p);
+            const bool want_logits = logits_out && row1 > row0;
+            const int r0 = row0 & ~31, nr = want_logits ? row1 - r0 : 0;
+            if (want_logits && d_logits_.n < (size_t)n * nr) d_logits_.alloc((size_t)n * nr);
+            if (want_logits || model_->fused) model_->head(st_, 0, n, want_logits ? r0 : 0, nr, d_logits_.p, nr, nullptr, -1, d_hid_.p);
+            Q3_HIP(hipStreamSynchronize(st_));
+            if (want_logits) {
                 std::vector<float> tmp((size_t)n * nr);
                 d_logits_.download(tmp.data(), tmp.size());
                 for (int i = 0; i < n; i++)
                     std::copy(tmp.begin() + (size_t)i * nr + (row0 - r0), tmp.begin() + (size_t)i * nr + (row0 - r0) + (row1 - row0),
                               logits_out + (size_t)(t0 + i) * (row1 - row0));
             }
-            Q3_HIP(hipStreamSynchronize(st_));
             if (hidden_out) d_hid_.download(hidden_out + (size_t)t0 * hp.n_embd, (size_t)n * hp.n_embd);
             n_past_ += n;
         }

@@ -132,7 +132,8 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     d_mrope_.alloc(4); d_mrope_.upload(hp_.mrope_sec, 4);
     nparts_d_ = ((ff >> 8) + 7) / 8;
     const size_t T = (size_t)max_tok;
-    h_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
+    scratch_.alloc(T * 32);
+    h_.alloc(T * d); h2_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
     qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
     const size_t mx = (size_t)(d > dq ? d : dq);
     xq_.alloc(T * mx); xd_.alloc(T * mx / 32); aq_.alloc(T * dq); ad_.alloc(T * dq / 32); fq_.alloc(T * ff); fd_.alloc(T * ff / 32);
@@ -148,6 +149,39 @@ void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, cons
 void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
     Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    last_fused_ = fused; last_ntok_ = ntok;
+    if (fused) {
+        // residual stream ping-pongs h_ <-> h2_: a fused prologue may not overwrite what other workgroups still read
+        for (int l = 0; l < hp_.n_layer; l++) {
+            const Layer& L = layers_[l];
+            NormPro a{};
+            if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx_keys = in.idx_keys; a.idx_stride = in.idx_stride; a.nparts = 0; }
+            else { a.h_in = h2_.p; a.h_stride = d; a.parts = parts_d_.p; a.nparts = nparts_d_; a.parts_stride = d; a.parts_slab = (size_t)ntok * d; }
+            a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps;
+            if (timer) timer->begin(st);
+            launch_gemv_q8_norm(st, L.wqkv, 0, dq + 2 * dkv, a, qkv_.p, dq + 2 * dkv, ntok, nullptr);
+            if (timer) timer->end(st, (double)L.wqkv.bytes());
+            if (same_seq_) {
+                launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
+                                      rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
+                launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
+            } else {
+                launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
+                                       rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
+            }
+            gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
+            NormPro b{};
+            b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.parts_slab = (size_t)ntok * d; b.h_out = h2_.p;
+            b.g = L.ffn_norm; b.eps = hp_.eps;
+            if (timer) timer->begin(st);
+            launch_gateup_swiglu(st, L.wgu, ff, b, fq_.p, fd_.p, ntok);
+            if (timer) timer->end(st, (double)L.wgu.bytes());
+            gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
+        }
+        // final norm is the prologue of head(); hidden_out is produced there too
+        if (hidden_out) head(st, 0, ntok, 0, 0, nullptr, 0, nullptr, -1, hidden_out);
+        return;
+    }
     for (int l = 0; l < hp_.n_layer; l++) {
         const Layer& L = layers_[l];
         NormArgs a{};
@@ -174,9 +208,30 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     launch_rmsnorm_quant(st, f, ntok);
 }
 
-void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride) {
+void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
+                       const ArgmaxEpi* am, int nrows_valid, float* hidden_out) {
     const int d = hp_.n_embd;
     Q3_CHECK(row0 % 32 == 0 && row0 + nrows <= output_.Npad, "head row range");
+    if (last_fused_) {
+        // final RMSNorm (+ last down-proj partials + residual) as the prologue of the output-matrix GEMV
+        NormPro f{};
+        f.h_in = h2_.p + (size_t)tok0 * d; f.h_stride = d;
+        f.parts = parts_d_.p + (size_t)tok0 * d; f.nparts = nparts_d_; f.parts_stride = d;
+        f.parts_slab = (size_t)last_ntok_ * d; // slabs are [p][ntok of the forward that wrote them][d]
+        f.g = output_norm_; f.eps = hp_.eps; f.xn_out = hidden_out;
+        if (nrows <= 0) { // hidden only: run the prologue through a 32-row GEMV whose output is discarded
+            if (timer) timer->begin(st);
+            launch_gemv_q8_norm(st, output_, 0, 32, f, scratch_logits(tok_count), 32, tok_count, nullptr);
+            if (timer) timer->end(st, 32.0 * ((double)d * 1.0625));
+            return;
+        }
+        if (timer) timer->begin(st);
+        if (am) launch_gemv_q8_norm(st, output_, row0, nrows_valid > 0 ? nrows_valid : nrows, f, nullptr, 0, tok_count, am);
+        else launch_gemv_q8_norm(st, output_, row0, nrows, f, logits, logits_stride, tok_count, nullptr);
+        if (timer) timer->end(st, (double)nrows * ((double)d * 1.0625));
+        return;
+    }
+    Q3_CHECK(am == nullptr, "argmax epilogue needs the fused path");
     gemv(st, output_, row0, nrows, xq_.p + (size_t)tok0 * d, xd_.p + (size_t)tok0 * (d / 32), logits, logits_stride, tok_count);
 }
 

@@ -27,13 +27,19 @@ public:
 
     struct Input {
         const float* x = nullptr; int x_stride = 0;   // [ntok][x_stride] embeddings ...
-        const int32_t* idx = nullptr; int idx_stride = 0; // ... or table rows: x + idx[tok*idx_stride]*x_stride
+        const int32_t* idx = nullptr; int idx_stride = 0; // ... or table rows: x + idx[tok*idx_stride]*x_stride (unfused path)
+        const q3_u64* idx_keys = nullptr;             // ... or table rows selected by argmax keys (fused path)
     };
+    // fused = 5 launches/layer (decode steps: every token from a different sequence, or a single sequence's
+    // tokens when `same_seq_tokens` is set, in which case attention stays unfused)
+    bool fused = true;
     // Runs all layers for ntok tokens.  After return (on stream): xq_/xd_ hold the quantised final-norm hidden of
     // every token; hidden_out (optional) gets the f32 final-norm hidden [ntok][n_embd].
     void forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out);
     // logits[tok_count][nrows] = output rows [row0,row0+nrows) . final hidden of tokens [tok0, tok0+tok_count)
-    void head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride);
+    void head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
+              const ArgmaxEpi* am = nullptr, int nrows_valid = -1, float* hidden_out = nullptr);
+    void set_same_seq_tokens(bool v) { same_seq_ = v; }
 
     LaunchTimer* timer = nullptr; // optional per-GEMV-launch event timing (instrumented bench leg)
     // op-level access for parity tests
@@ -42,6 +48,8 @@ public:
 
 private:
     struct Layer { Q8Mat wqkv, wo, wgu, wdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
+    float* scratch_logits(int) { return scratch_.p; }
+    DevBuf<float> scratch_;
     void gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
               int out_stride, int ntok);
     Q8Mat make_mat(int N, int K);
@@ -57,7 +65,8 @@ private:
     DevBuf<float> rope_cos_, rope_sin_;
     DevBuf<int32_t> d_mrope_;
     // activations
-    DevBuf<float> h_, parts_o_, parts_d_, qkv_, qrot_, gu_;
+    DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
+    bool same_seq_ = false; bool last_fused_ = false; int last_ntok_ = 0;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
     int nparts_d_ = 1;

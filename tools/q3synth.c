@@ -397,7 +397,7 @@ static void write_codec(const char* path, const ccfg* c, uint64_t seed) {
     }
     TT(0.1f, 0, ch, 1, 1, "codec.dec.snake_out.alpha");
     TT(0.1f, 0, ch, 1, 1, "codec.dec.snake_out.beta");
-    TT(0.3f / sqrtf(7.0f * ch), 0, 7, ch, 1, "codec.dec.conv_out.weight");
+    TT(0.1f / sqrtf(7.0f * ch), 0, 7, ch, 1, "codec.dec.conv_out.weight");
     TT(0.01f, 0, 1, 1, 1, "codec.dec.conv_out.bias");
 #undef TT
     if (gw_write(&g, path)) exit(1);
@@ -427,7 +427,7 @@ int main(int argc, char** argv) {
     } else if (!strcmp(preset, "tiny")) {
         talker = (tfcfg){ 2048, 2, 2, 1, 512, 3072, 1 };
         pred = (tfcfg){ 256, 2, 2, 1, 512, 30720, 0 };
-        codec = (ccfg){ 64, 32, 2, 2, 32, 128, 8, 64, 2, 4, { 2, 2 }, { 8, 5, 4, 3 } };
+        codec = (ccfg){ 64, 32, 2, 2, 32, 128, 8, 256, 2, 4, { 2, 2 }, { 8, 5, 4, 3 } };
     } else { fprintf(stderr, "unknown preset\n"); return 2; }
     const char* qdir = !strcmp(quant, "q8_0") ? "gguf_q8_0" : !strcmp(quant, "q5_k_m") ? "gguf_q5_k_m" : !strcmp(quant, "f32") ? "gguf" : !strcmp(quant, "bf16") ? "gguf_bf16" : "gguf_f16";
     char p[1024];
