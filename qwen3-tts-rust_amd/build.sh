@@ -18,4 +18,7 @@ done
 wait
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=$ARCH -o libq3tts.so $OBJS
 mkdir -p runtime && cp -f libq3tts.so runtime/libllama.so
+# host side: C++ mirror of the reference API + the Boundary-A replay harness (plain g++, no HIP)
+g++ -O2 -std=c++17 -fPIC -ffp-contract=off -shared -o libq3tts_host.so host/tts_engine.cpp -L. -lq3tts -Wl,-rpath,'$ORIGIN'
+g++ -O2 -std=c++17 -ffp-contract=off -o ref_replay host/ref_replay.cpp -ldl
 echo "built $(pwd)/libq3tts.so"

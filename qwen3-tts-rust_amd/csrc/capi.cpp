@@ -109,6 +109,18 @@ int q3tts_assets_codec_embedding(const q3tts_assets* a, int32_t q, int32_t code,
 int q3tts_assets_text_embedding(const q3tts_assets* a, int64_t tok, float* out) { Q3_API_BEGIN a->a->text_embedding(tok, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 int q3tts_assets_tts_pad(const q3tts_assets* a, float* out) { Q3_API_BEGIN std::copy(a->a->tts_pad(), a->a->tts_pad() + 2048, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 
+// host-side projection with the reference's exact loop (assets_manager.rs:383-399); used by the Boundary-A replay harness
+extern "C" int q3tts_assets_proj_out(const q3tts_assets* a) { return (int)a->a->proj_out; }
+extern "C" int q3tts_assets_project_host(const q3tts_assets* a, const float* x, float* out) {
+    const HostAssets& h = *a->a;
+    for (int64_t o = 0; o < h.proj_out; o++) {
+        float sum = h.proj_b[o];
+        const float* w = h.proj_w + (size_t)o * (size_t)h.proj_in;
+        for (int64_t i = 0; i < h.proj_in; i++) { const float t = x[i] * w[i]; sum = sum + t; }
+        out[o] = sum;
+    }
+    return Q3TTS_OK;
+}
 static int emit_rows(const PromptData& d, float* out, int32_t max_rows) {
     if (d.n_rows > max_rows) { set_last_error("prompt does not fit max_rows"); return -1; }
     std::copy(d.embd.begin(), d.embd.end(), out);

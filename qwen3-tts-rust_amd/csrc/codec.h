@@ -1,5 +1,5 @@
 // codec.h -- streaming codec decoder on device (codes -> 24 kHz PCM), the replacement for the ONNX AudioDecoder
-// (/root/reference/src/models/onnx.rs:324-496).  Architecture "Q3TTS-codec-synth" (oracle/q3o_codec.c).
+// (/root/reference/src/models/onnx.rs:324-496).  Architecture "Q3TTS-codec-synth" (see DESIGN.md).
 #pragma once
 #include "q3_common.h"
 #include <memory>

@@ -68,8 +68,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
         }
     }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < R * MT) {
+    for (int t = threadIdx.x; t < R * MT; t += blockDim.x) { // blockDim may be smaller than R*MT (few segments, many tokens)
         const int m = t / R, rr = t % R;
         int nsg = nseg - sseg * 8;
         if (nsg > 8) nsg = 8;

@@ -120,8 +120,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
         for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
     }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < R * MT) {
+    for (int t = threadIdx.x; t < R * MT; t += blockDim.x) { // whole R-lane groups stay together (blockDim % 64 == 0)
         const int m = t / R, rr = t % R;
         float S = red[0][t];
         for (int s = 1; s < nseg; s++) S = S + red[s][t];
@@ -214,8 +213,7 @@ __global__ void __launch_bounds__(512) k_gateup_swiglu(Q8Mat w, int ff, NormPro 
         if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
     }
     __syncthreads();
-    const int t = threadIdx.x;
-    if (t < 32 * MT) {
+    for (int t = threadIdx.x; t < 32 * MT; t += blockDim.x) {
         const int m = t >> 5, rr = t & 31, tok = tok0 + m;
         float G = red[0][0][t], U = red[0][1][t];
         for (int s = 1; s < nseg; s++) { G = G + red[s][0][t]; U = U + red[s][1][t]; }

@@ -1,0 +1,193 @@
+// tts_engine.cpp -- see tts_engine.hpp
+#include "tts_engine.hpp"
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <dirent.h>
+#include <fstream>
+#include <sstream>
+#include <stdexcept>
+
+namespace q3tts {
+
+// ---------------- minimal JSON (objects, arrays of numbers, strings) for VoiceFile ----------------
+namespace {
+struct JP {
+    const std::string& s; size_t i = 0;
+    void ws() { while (i < s.size() && (s[i] == ' ' || s[i] == '\n' || s[i] == '\t' || s[i] == '\r')) i++; }
+    [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json: ") + m + " at " + std::to_string(i)); }
+    char peek() { ws(); if (i >= s.size()) fail("eof"); return s[i]; }
+    void expect(char c) { if (peek() != c) fail("unexpected character"); i++; }
+    std::string str() {
+        expect('"');
+        std::string o;
+        while (i < s.size() && s[i] != '"') {
+            if (s[i] == '\\' && i + 1 < s.size()) { char c = s[++i]; o += c == 'n' ? '\n' : c == 't' ? '\t' : c; i++; }
+            else o += s[i++];
+        }
+        if (i >= s.size()) fail("unterminated string");
+        i++;
+        return o;
+    }
+    double num() { ws(); size_t st = i; while (i < s.size() && (isdigit((unsigned char)s[i]) || strchr("+-.eE", s[i]))) i++; if (st == i) fail("number"); return std::stod(s.substr(st, i - st)); }
+    void skip() { // any value
+        char c = peek();
+        if (c == '"') { str(); return; }
+        if (c == '{') { i++; if (peek() == '}') { i++; return; } for (;;) { str(); expect(':'); skip(); if (peek() == ',') { i++; continue; } expect('}'); return; } }
+        if (c == '[') { i++; if (peek() == ']') { i++; return; } for (;;) { skip(); if (peek() == ',') { i++; continue; } expect(']'); return; } }
+        if (!strncmp(s.c_str() + i, "true", 4)) { i += 4; return; }
+        if (!strncmp(s.c_str() + i, "false", 5)) { i += 5; return; }
+        if (!strncmp(s.c_str() + i, "null", 4)) { i += 4; return; }
+        num();
+    }
+    template <typename T> std::vector<T> arr() {
+        std::vector<T> v;
+        expect('[');
+        if (peek() == ']') { i++; return v; }
+        for (;;) { v.push_back((T)num()); if (peek() == ',') { i++; continue; } expect(']'); return v; }
+    }
+    std::optional<std::string> optstr() { if (peek() == 'n') { i += 4; return std::nullopt; } return str(); }
+};
+std::string esc(const std::string& s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o; }
+}
+
+VoiceFile VoiceFile::load(const std::string& path) {
+    std::ifstream f(path);
+    if (!f) throw std::runtime_error("No such file or directory: " + path);
+    std::stringstream ss; ss << f.rdbuf();
+    const std::string txt = ss.str();
+    JP p{txt};
+    VoiceFile v;
+    bool have_emb = false;
+    p.expect('{');
+    if (p.peek() != '}') for (;;) {
+        const std::string k = p.str();
+        p.expect(':');
+        if (k == "ref_text") v.ref_text = p.str();
+        else if (k == "audio_codes") v.audio_codes = p.arr<int64_t>();
+        else if (k == "speaker_embedding" || k == "spk_emb") { v.speaker_embedding = p.arr<float>(); have_emb = true; } // serde alias, voice_file.rs:13
+        else if (k == "name") v.name = p.optstr();
+        else if (k == "gender") v.gender = p.optstr();
+        else if (k == "age") v.age = p.optstr();
+        else if (k == "description") v.description = p.optstr();
+        else p.skip(); // unknown keys (e.g. spk_id) are dropped, like serde's default
+        if (p.peek() == ',') { p.i++; continue; }
+        p.expect('}');
+        break;
+    } else p.i++;
+    if (!have_emb) throw std::runtime_error("missing field `speaker_embedding`");
+    return v;
+}
+void VoiceFile::save(const std::string& path) const {
+    std::ofstream f(path);
+    if (!f) throw std::runtime_error("cannot create " + path);
+    f << "{\n  \"ref_text\": \"" << esc(ref_text) << "\",\n  \"audio_codes\": [";
+    for (size_t i = 0; i < audio_codes.size(); i++) f << (i ? ", " : "") << audio_codes[i];
+    f << "],\n  \"speaker_embedding\": [";
+    f.precision(9);
+    for (size_t i = 0; i < speaker_embedding.size(); i++) f << (i ? ", " : "") << speaker_embedding[i];
+    f << "]";
+    auto opt = [&](const char* k, const std::optional<std::string>& v) { f << ",\n  \"" << k << "\": "; if (v) f << "\"" << esc(*v) << "\""; else f << "null"; };
+    opt("name", name); opt("gender", gender); opt("age", age); opt("description", description);
+    f << "\n}\n";
+}
+
+void AudioSample::save_wav(const std::string& path) const { // audio.rs:26-41
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot create " + path);
+    const uint32_t data_bytes = (uint32_t)samples.size() * 2, riff = 36 + data_bytes, fmt_len = 16, byte_rate = sample_rate * channels * 2;
+    const uint16_t pcm = 1, block = (uint16_t)(channels * 2), bits = 16;
+    fwrite("RIFF", 1, 4, f); fwrite(&riff, 4, 1, f); fwrite("WAVEfmt ", 1, 8, f); fwrite(&fmt_len, 4, 1, f); fwrite(&pcm, 2, 1, f);
+    fwrite(&channels, 2, 1, f); fwrite(&sample_rate, 4, 1, f); fwrite(&byte_rate, 4, 1, f); fwrite(&block, 2, 1, f); fwrite(&bits, 2, 1, f);
+    fwrite("data", 1, 4, f); fwrite(&data_bytes, 4, 1, f);
+    for (float s : samples) { float a = s * 32767.0f; a = a < -32768.0f ? -32768.0f : (a > 32767.0f ? 32767.0f : a); const int16_t v = (int16_t)a; fwrite(&v, 2, 1, f); }
+    fclose(f);
+}
+
+TtsEngine TtsEngine::new_(const std::string& model_dir, const std::string& quant, Tokenizer tok) {
+    TtsEngine t;
+    q3tts_engine_params p;
+    q3tts_engine_params_default(&p);
+    p.model_dir = model_dir.c_str(); p.quant = quant.c_str(); p.max_batch = 1;
+    if (q3tts_engine_create(&p, &t.e_) != Q3TTS_OK) throw std::runtime_error(std::string("Failed to load TtsEngine: ") + q3tts_last_error());
+    t.tok_ = std::move(tok);
+    // engine.rs:156-166: <model_dir>/preset_speakers, else ./speakers
+    for (const std::string& d : {model_dir + "/preset_speakers", std::string("speakers")}) {
+        if (DIR* dd = opendir(d.c_str())) { closedir(dd); t.load_speakers(d); break; }
+    }
+    return t;
+}
+TtsEngine::TtsEngine(TtsEngine&& o) noexcept { *this = std::move(o); }
+TtsEngine& TtsEngine::operator=(TtsEngine&& o) noexcept {
+    if (this != &o) { if (e_) q3tts_engine_destroy(e_); e_ = o.e_; o.e_ = nullptr; tok_ = std::move(o.tok_); speakers_ = std::move(o.speakers_); max_steps_ = o.max_steps_; sampler_ = o.sampler_; }
+    return *this;
+}
+TtsEngine::~TtsEngine() { if (e_) q3tts_engine_destroy(e_); }
+
+void TtsEngine::load_speakers(const std::string& dir) {
+    DIR* d = opendir(dir.c_str());
+    if (!d) throw std::runtime_error("cannot read " + dir);
+    while (dirent* e = readdir(d)) {
+        const std::string n = e->d_name;
+        if (n.size() > 5 && n.substr(n.size() - 5) == ".json") {
+            try { speakers_[n.substr(0, n.size() - 5)] = VoiceFile::load(dir + "/" + n); } catch (...) {} // `if let Ok(voice)`, :196
+        }
+    }
+    closedir(d);
+}
+const VoiceFile& TtsEngine::get_speaker(const std::string& id) const {
+    auto it = speakers_.find(id);
+    if (it != speakers_.end()) return it->second;
+    for (auto& kv : speakers_) if (kv.second.name && *kv.second.name == id) return kv.second;
+    it = speakers_.find("vivian");
+    if (it != speakers_.end()) return it->second;
+    if (speakers_.empty()) throw std::runtime_error("No speakers loaded in engine!");
+    return speakers_.begin()->second;
+}
+
+AudioSample TtsEngine::generate_with_voice(const std::string& text, const VoiceFile& voice, const std::optional<std::string>& instruct) {
+    if (!tok_) throw std::runtime_error("no tokenizer attached (SURVEY row f-3): use generate_with_voice_ids");
+    const auto ids = tok_(text);
+    std::vector<int32_t> ins, rt;
+    if (instruct) ins = tok_(*instruct);
+    if (!voice.audio_codes.empty()) rt = tok_(voice.ref_text);
+    return generate_with_voice_ids(ids, voice, instruct ? &ins : nullptr, voice.audio_codes.empty() ? nullptr : &rt);
+}
+
+AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins,
+                                               const std::vector<int32_t>* ref_text_ids, std::vector<int32_t>* codes_out) {
+    const q3tts_assets* a = q3tts_engine_assets(e_);
+    const int max_rows = 1024;
+    std::vector<float> prompt((size_t)max_rows * 2048);
+    int n;
+    if (voice.audio_codes.empty()) // engine.rs:398-412: Chinese lang id 2055, speaker injected as marker + spk_emb
+        n = q3tts_prompt_build_core(a, text_ids.data(), (int)text_ids.size(), 2055, -1, voice.speaker_embedding.data(), ins ? ins->data() : nullptr,
+                                    ins ? (int)ins->size() : 0, nullptr, 0, prompt.data(), max_rows);
+    else { // :413-427
+        std::vector<int32_t> rc(voice.audio_codes.begin(), voice.audio_codes.end()), rt;
+        if (ref_text_ids) rt = *ref_text_ids;
+        n = q3tts_prompt_build_clone(a, text_ids.data(), (int)text_ids.size(), rc.data(), (int)rc.size(), rt.data(), (int)rt.size(),
+                                     voice.speaker_embedding.data(), 2055, ins ? ins->data() : nullptr, ins ? (int)ins->size() : 0, prompt.data(), max_rows);
+    }
+    if (n < 0) throw std::runtime_error(q3tts_last_error());
+    q3tts_request r{};
+    r.prompt = prompt.data(); r.n_prompt = n; r.max_steps = (int)max_steps_;
+    r.sampler.temperature = sampler_.temperature; r.sampler.top_k = sampler_.top_k; r.sampler.top_p = sampler_.top_p;
+    r.sampler.has_seed = sampler_.seed ? 1 : 0; r.sampler.seed = sampler_.seed.value_or(0);
+    std::vector<int32_t> codes(max_steps_ * 16);
+    AudioSample out;
+    out.samples.resize(max_steps_ * 1920);
+    r.codes_out = codes.data(); r.pcm_out = out.samples.data(); r.pcm_capacity = (int64_t)out.samples.size();
+    if (q3tts_generate_batch(e_, &r, 1, 1) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    out.samples.resize((size_t)r.n_pcm);
+    if (codes_out) codes_out->assign(codes.begin(), codes.begin() + (size_t)r.n_frames * 16);
+    return out; // AudioSample{samples, 24000, 1}: engine.rs:651-655
+}
+
+VoiceFile TtsEngine::create_voice_file(const std::string&, const std::string&) {
+    // engine.rs:329-334: the reference returns Err when its ONNX encoders are absent; this build never has them.
+    throw std::runtime_error("AudioEncoder not loaded. Please ensure models/onnx/qwen3_tts_codec_encoder.onnx exists.");
+}
+
+} // namespace q3tts

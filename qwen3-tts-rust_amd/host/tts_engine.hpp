@@ -1,0 +1,67 @@
+// tts_engine.hpp -- C++ mirror of the reference's public Rust API over the C ABI (include/q3tts.h).
+// The reference's host language (Rust, edition 2024) has no toolchain in this image, so the host side above the
+// C ABI is C++ with the same names, argument meaning and error behaviour:
+//   SamplerConfig            /root/reference/src/tts/engine.rs:13-45
+//   VoiceFile                /root/reference/src/utils/voice_file.rs:5-62  (JSON, alias spk_emb, unknown keys ignored)
+//   AudioSample              /root/reference/src/utils/audio.rs:4-46       (save_wav: i16, x32767 clamp)
+//   TtsEngine::{new_, set_max_steps, set_sampler_config, get_sampler_config, load_speakers, get_speaker,
+//               generate_with_voice, create_voice_file}   /root/reference/src/tts/engine.rs:84-435
+// Text -> token ids (HF tokenizers crate, src/utils/tokenizer.rs) is SURVEY row f-3 and stays pluggable.
+#pragma once
+#include "../../include/q3tts.h"
+#include <functional>
+#include <map>
+#include <optional>
+#include <string>
+#include <vector>
+
+namespace q3tts {
+
+struct SamplerConfig { // engine.rs:13-45
+    float temperature = 0.7f; int top_k = 40; float top_p = 0.9f; std::optional<uint64_t> seed;
+};
+
+struct VoiceFile { // voice_file.rs:5-22
+    std::string ref_text; std::vector<int64_t> audio_codes; std::vector<float> speaker_embedding;
+    std::optional<std::string> name, gender, age, description;
+    static VoiceFile load(const std::string& path);   // throws std::runtime_error with the parse error
+    void save(const std::string& path) const;
+};
+
+struct AudioSample { // audio.rs:4-46
+    std::vector<float> samples; uint32_t sample_rate = 24000; uint16_t channels = 1;
+    void save_wav(const std::string& path) const;
+    float duration() const { return (float)samples.size() / (float)sample_rate; }
+};
+
+using Tokenizer = std::function<std::vector<int32_t>(const std::string&)>;
+
+class TtsEngine {
+public:
+    // TtsEngine::new(model_dir, quant) -- engine.rs:84-169 (no downloader: local paths only)
+    static TtsEngine new_(const std::string& model_dir, const std::string& quant, Tokenizer tok = nullptr);
+    TtsEngine(TtsEngine&&) noexcept; TtsEngine& operator=(TtsEngine&&) noexcept;
+    TtsEngine(const TtsEngine&) = delete;
+    ~TtsEngine();
+    void set_max_steps(size_t steps) { max_steps_ = steps; }                       // :172-174
+    void set_sampler_config(const SamplerConfig& c) { sampler_ = c; }              // :177-179
+    const SamplerConfig& get_sampler_config() const { return sampler_; }           // :182-184
+    void load_speakers(const std::string& dir);                                    // :187-208
+    const VoiceFile& get_speaker(const std::string& id_or_name) const;             // :211-231 (vivian fallback)
+    // generate_with_voice -- :390-435; text goes through the pluggable tokenizer
+    AudioSample generate_with_voice(const std::string& text, const VoiceFile& voice, const std::optional<std::string>& instruct = std::nullopt);
+    AudioSample generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice,
+                                        const std::vector<int32_t>* instruct_ids = nullptr, const std::vector<int32_t>* ref_text_ids = nullptr,
+                                        std::vector<int32_t>* codes_out = nullptr);
+    // create_voice_file -- :324-387: needs the codec/speaker encoder graphs (not in this build)
+    VoiceFile create_voice_file(const std::string& audio_path, const std::string& ref_text);
+private:
+    TtsEngine() = default;
+    q3tts_engine* e_ = nullptr;
+    Tokenizer tok_;
+    std::map<std::string, VoiceFile> speakers_;
+    size_t max_steps_ = 512;
+    SamplerConfig sampler_;
+};
+
+} // namespace q3tts

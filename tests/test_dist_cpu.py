@@ -1,0 +1,60 @@
+"""N>1 path on CPU: world_size-2 gloo.  Covers the one collective of the hot path (voice broadcast) and the
+round-robin request sharding that bench.py / the serving loop use across GPUs."""
+import os
+import sys
+import numpy as np
+import pytest
+
+torch = pytest.importorskip("torch")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.join(ROOT, "qwen3-tts-rust_amd", "python"))
+    from q3tts.dist import broadcast_voice, shard_requests
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    rng = np.random.default_rng(123)
+    emb = rng.standard_normal(2048).astype(np.float32)
+    codes = rng.integers(0, 2048, 62 * 16)
+    ids = rng.integers(0, 151000, 24)
+    if rank == 0:
+        e, c, t = broadcast_voice(emb, codes, ids, src=0)
+        e2, c2, t2 = broadcast_voice(emb, None, None, src=0)           # preset voice: embedding only
+    else:
+        e, c, t = broadcast_voice(None, None, None, src=0)
+        e2, c2, t2 = broadcast_voice(None, None, None, src=0)
+    mine = shard_requests(7, rank, world)
+    # weak-scaling bookkeeping the bench does: max over ranks of the elapsed time
+    tt = torch.tensor([1.0 + rank], dtype=torch.float64)
+    dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+    q.put((rank, np.array_equal(e, emb), np.array_equal(c, codes), np.array_equal(t, ids), np.array_equal(e2, emb), c2.size, t2.size,
+           mine, float(tt.item())))
+    dist.destroy_process_group()
+
+
+def test_voice_broadcast_and_sharding_world2():
+    import torch.multiprocessing as mp
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = 29500 + os.getpid() % 2000
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(2))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, ok_e, ok_c, ok_t, ok_e2, nc2, nt2, mine, tmax in res:
+        assert ok_e and ok_c and ok_t and ok_e2 and nc2 == 0 and nt2 == 0 and tmax == 2.0
+    assert res[0][7] == [0, 2, 4, 6] and res[1][7] == [1, 3, 5]
+
+
+def test_single_process_passthrough():
+    sys.path.insert(0, os.path.join(ROOT, "qwen3-tts-rust_amd", "python"))
+    from q3tts.dist import broadcast_voice, shard_requests
+    e, c, t = broadcast_voice(np.ones(2048, np.float32), [1, 2], None)
+    assert e.shape == (2048,) and c.tolist() == [1, 2] and t.size == 0
+    assert shard_requests(5, 0, 1) == [0, 1, 2, 3, 4]

@@ -1,0 +1,45 @@
+"""The oracle must keep reproducing the committed golden vectors (tests/golden/oracle_tiny_v1.npz, made by
+tests/golden/make_golden.py from the seeded tiny model)."""
+import os
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "oracle_tiny_v1.npz")
+
+
+def test_oracle_reproduces_golden(tiny_model, oracle, vivian):
+    g = np.load(GOLD)
+    eng = oracle.Engine(os.path.join(tiny_model, "gguf_q8_0"), os.path.join(tiny_model, "onnx", "q3tts_codec.gguf"), 4)
+    prompt = eng.assets.build_core(np.arange(100, 108, dtype=np.int32), lang_id=2055, spk_emb=vivian)
+    assert np.allclose([prompt.astype(np.float64).sum(), np.abs(prompt).astype(np.float64).sum()], g["prompt_checksum"], rtol=0, atol=0)
+    codes, pcm = eng.generate(prompt, max_steps=12, temperature=0.0, seed=42, mask_eos=True, want_pcm=True)
+    assert np.array_equal(codes, g["greedy_codes"])
+    assert np.array_equal(pcm[:4096], g["greedy_pcm_head"]) and pcm.size == int(g["greedy_pcm_stats"][0])
+    codes_s, _ = eng.generate(prompt, max_steps=12, temperature=0.7, top_k=40, top_p=0.9, seed=42, mask_eos=True)
+    assert np.array_equal(codes_s, g["sampled_codes"])
+    assert not np.array_equal(codes_s, codes)
+    assert np.array_equal(eng.assets.project(vivian)[:256], g["project_vivian"])
+    eng.close()
+    m = oracle.Model(os.path.join(tiny_model, "gguf_q8_0", "qwen3_tts_talker.gguf"), 64)
+    for t in range(3):
+        h, l = m.eval(prompt[t], [t, t, t, 0], 2048, 0, 2160)
+        assert np.array_equal(h, g["talker_hidden3"][t]) and np.array_equal(l, g["talker_logits3"][t])
+    m.close()
+    lg = np.sin(np.arange(2160, dtype=np.float32) * 0.37) * 3
+    kat = [oracle.sample(lg, 0, 2160, temperature=0.7, top_k=40, top_p=0.9, seed=s)[0] for s in range(16)]
+    assert kat == g["sampler_kat"].tolist()
+
+
+def test_q5_k_m_and_bf16_oracle_paths_run(tiny_model, oracle, vivian):
+    """configs[0] (Q5_K_M, CPU) and the bf16 path of config 5 run through the oracle; different quantisations of the same
+    seeded weights give different but equally long greedy runs."""
+    runs = {}
+    for sub in ("gguf_q8_0", "gguf_q5_k_m", "gguf_bf16"):
+        qdir = os.path.join(tiny_model, sub)
+        if not os.path.exists(os.path.join(qdir, "qwen3_assets.gguf")):
+            os.symlink(os.path.join(tiny_model, "gguf_q8_0", "qwen3_assets.gguf"), os.path.join(qdir, "qwen3_assets.gguf"))
+        eng = oracle.Engine(qdir, None, 4)
+        prompt = eng.assets.build_core(np.arange(100, 108, dtype=np.int32), lang_id=2055, spk_emb=vivian)
+        runs[sub], _ = eng.generate(prompt, max_steps=4, temperature=0.0, seed=42, mask_eos=True)
+        eng.close()
+        assert runs[sub].shape == (4, 16) and runs[sub].min() >= 0 and runs[sub][:, 1:].max() < 2048 and runs[sub][:, 0].max() < 2160

@@ -1,0 +1,221 @@
+"""GPU parity tests (run with -m gpu on an MI355X): every call goes through the C ABI of libq3tts.so; the expected
+values come from the CPU oracle on the same seeded inputs and from the committed golden fixtures.
+Bars: codec tokens / int8 quantisation / argmax indices bit-exact; f32 intermediates bit-exact (the arithmetic spec fixes
+every reduction order); PCM within 1e-4 RMS (BASELINE.json north_star)."""
+import os
+import subprocess
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+GOLD = os.path.join(ROOT, "tests", "golden", "oracle_tiny_v1.npz")
+PCM_RMS_TOL = 1e-4
+
+
+def _q8_encode(w):
+    n, k = w.shape
+    wb = w.reshape(n, k // 32, 32)
+    d = (np.abs(wb).max(-1) / 127).astype(np.float32)
+    idv = np.where(d > 0, 1.0 / np.where(d > 0, d, 1), 0).astype(np.float32)
+    q = np.rint(wb * idv[..., None]).astype(np.int8)
+    raw = np.zeros((n, k // 32, 34), np.uint8)
+    raw[..., :2] = d.astype(np.float16).view(np.uint8).reshape(n, k // 32, 2)
+    raw[..., 2:] = q.view(np.uint8)
+    return raw
+
+
+def _bits(a):
+    return np.ascontiguousarray(a, np.float32).view(np.uint32)
+
+
+@pytest.mark.parametrize("n,k,ntok", [(32, 256, 1), (96, 2048, 1), (4096, 2048, 1), (256, 6144, 3), (2048, 1024, 2), (160, 3072, 9), (40, 512, 5)])
+def test_gemv_q8_bit_exact(gpu, oracle, n, k, ntok):
+    rng = np.random.default_rng(n + k)
+    raw = _q8_encode((rng.standard_normal((n, k)) * 0.02).astype(np.float32))
+    x = (rng.standard_normal((ntok, k)) * rng.uniform(0.1, 4)).astype(np.float32)
+    L = oracle.lib()
+    xq = np.zeros((ntok, k), np.int8); xd = np.zeros((ntok, k // 32), np.uint16); yo = np.zeros((ntok, n), np.float32)
+    for t in range(ntok):
+        L.q3o_quant_act(x[t].ctypes.data, k, xq[t].ctypes.data, xd[t].ctypes.data)
+        L.q3o_matvec(8, raw.ctypes.data, n, k, xq[t].ctypes.data, xd[t].ctypes.data, None, yo[t].ctypes.data)
+    for lpr in (2, 4, 8, 0):
+        assert np.array_equal(_bits(gpu.op_gemv_q8(raw, n, k, xq, xd, lpr)), _bits(yo)), lpr
+
+
+@pytest.mark.parametrize("d", [256, 1024, 2048])
+def test_rmsnorm_quant_bit_exact(gpu, oracle, d):
+    rng = np.random.default_rng(d)
+    x = (rng.standard_normal((4, d)) * 3).astype(np.float32)
+    x[3] = 0.0   # all-zero row: d = 0 branch of the block quantiser
+    g = (1 + 0.1 * rng.standard_normal(d)).astype(np.float32)
+    xq, xd, xn = gpu.op_rmsnorm_quant(x, g, 1e-6)
+    L = oracle.lib()
+    for t in range(4):
+        y = np.zeros(d, np.float32); L.q3o_rmsnorm(x[t].ctypes.data, g.ctypes.data, d, 1e-6, y.ctypes.data)
+        q = np.zeros(d, np.int8); dd = np.zeros(d // 32, np.uint16); L.q3o_quant_act(y.ctypes.data, d, q.ctypes.data, dd.ctypes.data)
+        assert np.array_equal(_bits(y), _bits(xn[t])) and np.array_equal(q, xq[t]) and np.array_equal(dd, xd[t])
+
+
+def test_swiglu_argmax_project(gpu, oracle, tiny_model, vivian):
+    import ctypes as C
+    rng = np.random.default_rng(5)
+    ff = 512
+    gu = (rng.standard_normal((3, 2 * ff)) * 3).astype(np.float32)
+    gu[0, :4] = [-200.0, 200.0, 0.0, -0.0]
+    aq, ad = gpu.op_swiglu_quant(gu, ff)
+    L = oracle.lib()
+    L.q3o_spec_swiglu.restype = C.c_float; L.q3o_spec_swiglu.argtypes = [C.c_float, C.c_float]
+    for t in range(3):
+        a = np.array([L.q3o_spec_swiglu(float(gu[t, i]), float(gu[t, ff + i])) for i in range(ff)], np.float32)
+        q = np.zeros(ff, np.int8); dd = np.zeros(ff // 32, np.uint16); L.q3o_quant_act(a.ctypes.data, ff, q.ctypes.data, dd.ctypes.data)
+        assert np.array_equal(q, aq[t]) and np.array_equal(dd, ad[t])
+    lg = np.zeros(3072, np.float32); lg[[5, 9, 2150, 2500]] = [3.0, 3.0, 9.0, 100.0]
+    assert gpu.op_argmax(lg, 0, 2160) == 2150 and gpu.op_argmax(lg, 0, 2160, mask_idx=2150) == 5 and gpu.op_argmax(lg, 6, 2160, 2150) == 9
+    assert gpu.op_argmax(np.full(300, -np.inf, np.float32), 10, 290) == 10
+    for _ in range(20):
+        v = rng.standard_normal(2160).astype(np.float32); v[rng.integers(0, 2160, 40)] = v.max()
+        assert gpu.op_argmax(v, 0, 2160) == int(np.argmax(v))
+    import ggml_ref as G
+    _, t = G.read_gguf(os.path.join(tiny_model, "gguf_q8_0", "qwen3_assets.gguf"))
+    W = np.array(t["proj.weight"][2]).view(np.float32).reshape(-1, 2048); b = np.array(t["proj.bias"][2]).view(np.float32)
+    oa = oracle.Assets(os.path.join(tiny_model, "gguf_q8_0", "qwen3_assets.gguf"))
+    assert np.array_equal(_bits(gpu.op_project(vivian, W, b)), _bits(oa.project(vivian)[: b.size]))
+    oa.close()
+
+
+def _tf_parity(gpu, oracle, path, d, n_pre, n_dec, rows):
+    rng = np.random.default_rng(9)
+    om = oracle.Model(path, 4096)
+    gm = gpu.TfContext(path, 4096, 16)
+    xs = (rng.standard_normal((n_pre + n_dec, d)) * 0.3).astype(np.float32)
+    pos = np.array([[t, t, t, 0] for t in range(n_pre + n_dec)], np.int32)
+    hg, lg = gm.eval(xs[:n_pre], pos[:n_pre], 0, rows)       # chunked prefill (16 tokens per launch)
+    for t in range(n_pre):
+        ho, lo = om.eval(xs[t], pos[t], d, 0, rows)
+        assert np.array_equal(_bits(ho), _bits(hg[t])) and np.array_equal(_bits(lo), _bits(lg[t])), t
+    for t in range(n_pre, n_pre + n_dec):
+        h1, l1 = gm.eval(xs[t:t + 1], pos[t:t + 1], 0, rows)
+        ho, lo = om.eval(xs[t], pos[t], d, 0, rows)
+        assert np.array_equal(_bits(ho), _bits(h1[0])) and np.array_equal(_bits(lo), _bits(l1[0])), t
+    gm.clear(); om.clear()   # llama_memory_seq_rm(-1,0,-1) semantics: positions restart
+    h2, _ = gm.eval(xs[:1], pos[:1], 0, 0)
+    ho, _ = om.eval(xs[0], pos[0], d, 0, 0)
+    assert np.array_equal(_bits(ho), _bits(h2[0]))
+    gm.close(); om.close()
+
+
+def test_transformer_fused_path_bit_exact(gpu, oracle, tiny_model):
+    _tf_parity(gpu, oracle, os.path.join(tiny_model, "gguf_q8_0", "qwen3_tts_talker.gguf"), 2048, 37, 5, 2160)
+    _tf_parity(gpu, oracle, os.path.join(tiny_model, "gguf_q8_0", "qwen3_tts_predictor.gguf"), 256, 2, 14, 2048)
+
+
+def test_transformer_unfused_path_bit_exact(gpu, oracle, tiny_model):
+    os.environ["Q3_UNFUSED"] = "1"
+    try:
+        _tf_parity(gpu, oracle, os.path.join(tiny_model, "gguf_q8_0", "qwen3_tts_talker.gguf"), 2048, 20, 3, 2160)
+    finally:
+        del os.environ["Q3_UNFUSED"]
+
+
+def test_attention_beyond_one_chunk(gpu, oracle, tiny_model):
+    """context > 256 positions exercises the chunk-merge branch of spec S7 (rule: a rare branch needs its own test)."""
+    path = os.path.join(tiny_model, "gguf_q8_0", "qwen3_tts_talker.gguf")
+    rng = np.random.default_rng(10)
+    om = oracle.Model(path, 4096); gm = gpu.TfContext(path, 4096, 64)
+    n = 300
+    xs = (rng.standard_normal((n + 2, 2048)) * 0.3).astype(np.float32)
+    pos = np.array([[t, t, t, 0] for t in range(n + 2)], np.int32)
+    hg, _ = gm.eval(xs[:n], pos[:n])
+    for t in range(n):
+        ho, _ = om.eval(xs[t], pos[t], 2048)
+        if t in (0, 255, 256, 257, n - 1):
+            assert np.array_equal(_bits(ho), _bits(hg[t])), t
+    for t in (n, n + 1):   # fused decode kernel with 2 chunks
+        h1, _ = gm.eval(xs[t:t + 1], pos[t:t + 1]); ho, _ = om.eval(xs[t], pos[t], 2048)
+        assert np.array_equal(_bits(ho), _bits(h1[0]))
+    gm.close(); om.close()
+
+
+@pytest.fixture(scope="module")
+def tiny_engines(gpu, oracle, tiny_model):
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=4, max_steps=64, load_codec=True)
+    oe = oracle.Engine(os.path.join(tiny_model, "gguf_q8_0"), os.path.join(tiny_model, "onnx", "q3tts_codec.gguf"), 4)
+    yield ge, oe
+    ge.close(); oe.close()
+
+
+def test_engine_matches_golden_and_oracle(tiny_engines, vivian):
+    ge, oe = tiny_engines
+    g = np.load(GOLD)
+    prompt = ge.assets.build_core(np.arange(100, 108, dtype=np.int32), lang_id=2055, spk_emb=vivian)
+    r = ge.generate_batch([prompt], max_steps=12, temperature=0.0, seed=42, mask_eos=True, want_pcm=True)[0]
+    assert np.array_equal(r["codes"], g["greedy_codes"])                       # bit-exact codec tokens vs committed fixture
+    assert r["pcm"].size == int(g["greedy_pcm_stats"][0])
+    assert np.sqrt(np.mean((r["pcm"][:4096] - g["greedy_pcm_head"]) ** 2)) < PCM_RMS_TOL
+    oc, opcm = oe.generate(prompt, max_steps=12, want_pcm=True)
+    assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
+    # temperature > 0: host sampler on device logits (seeded StdRng stream)
+    rs = ge.generate_batch([prompt], max_steps=12, temperature=0.7, top_k=40, top_p=0.9, seed=42, mask_eos=True)[0]
+    assert np.array_equal(rs["codes"], g["sampled_codes"])
+    # determinism
+    assert np.array_equal(ge.generate_batch([prompt], max_steps=12)[0]["codes"], r["codes"])
+
+
+def test_engine_eos_and_ragged_lengths(tiny_engines, vivian):
+    ge, oe = tiny_engines
+    rng = np.random.default_rng(3)
+    for n_text, steps in ((1, 5), (40, 9), (3, 10), (17, 7)):   # frame counts 5,9,10,7: leftover-flush and no-flush chunker paths
+        prompt = ge.assets.build_core(rng.integers(0, 4000, n_text).astype(np.int32), lang_id=2055, spk_emb=vivian)
+        r = ge.generate_batch([prompt], max_steps=steps, mask_eos=False, want_pcm=True)[0]    # natural EOS allowed
+        oc, opcm = oe.generate(prompt, max_steps=steps, mask_eos=False, want_pcm=True)
+        assert np.array_equal(oc, r["codes"])
+        assert r["pcm"].size == opcm.size and (opcm.size == 0 or np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL)
+    prompt = ge.assets.build_core(np.array([5], np.int32), lang_id=2055, spk_emb=vivian)
+    assert ge.generate_batch([prompt], max_steps=0)[0]["codes"].shape == (0, 16)          # empty generation
+
+
+def test_engine_batch_equals_singles(tiny_engines, vivian):
+    """request-level batching: B lock-stepped sequences (different prompt lengths, one clone prompt) give the same tokens as
+    one-at-a-time runs -- batch invariance of the arithmetic spec."""
+    ge, oe = tiny_engines
+    rng = np.random.default_rng(4)
+    prompts = [ge.assets.build_core(rng.integers(0, 4000, n).astype(np.int32), lang_id=2055, spk_emb=vivian) for n in (4, 19, 33)]
+    prompts.append(ge.assets.build_clone(rng.integers(0, 4000, 6).astype(np.int32), rng.integers(0, 2048, 5 * 16), rng.integers(0, 4000, 3), vivian))
+    batch = ge.generate_batch(prompts, max_steps=10, mask_eos=True, want_pcm=True)
+    for p, r in zip(prompts, batch):
+        oc, opcm = oe.generate(p, max_steps=10, want_pcm=True)
+        assert np.array_equal(oc, r["codes"])
+        assert np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
+    two = ge.generate_batch(prompts[:2], max_steps=10, mask_eos=True)
+    assert all(np.array_equal(a["codes"], b["codes"]) for a, b in zip(two, batch))
+
+
+def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
+    path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
+    rng = np.random.default_rng(8)
+    codes = rng.integers(-3, 2051, (23, 16))      # out-of-range codes are clamped like engine.rs:515-519 would
+    oc = oracle.Codec(path); oc.reset(); ref = oc.decode(np.clip(codes, 0, 2047)).copy(); oc.close()
+    gd = gpu.Decoder(path, 2)
+    for stream, chunks in ((0, [4, 4, 4, 4, 4, 3]), (1, [1, 22])):
+        gd.reset(stream)
+        o, parts = 0, []
+        for i, n in enumerate(chunks):
+            parts.append(gd.decode(np.clip(codes[o:o + n], 0, 2047), i == len(chunks) - 1, stream)); o += n
+        got = np.concatenate(parts)
+        assert got.shape == ref.shape and np.sqrt(np.mean((got - ref) ** 2)) < PCM_RMS_TOL and np.abs(got - ref).max() < 1e-3
+    gd.close()
+
+
+def test_llama_abi_replay_matches_oracle(gpu, oracle, tiny_model, vivian, tmp_path):
+    """Boundary A: the reference's loop, replayed call-for-call through runtime/libllama.so (dlopen'd from cwd/runtime)."""
+    pkg = os.path.join(ROOT, "qwen3-tts-rust_amd")
+    oe = oracle.Engine(os.path.join(tiny_model, "gguf_q8_0"), None, 4)
+    prompt = oe.assets.build_core(np.arange(50, 61, dtype=np.int32), lang_id=2055, spk_emb=vivian)
+    oc, _ = oe.generate(prompt, max_steps=6, mask_eos=True)
+    oe.close()
+    pf, cf = str(tmp_path / "prompt.f32"), str(tmp_path / "codes.i32")
+    prompt.tofile(pf)
+    subprocess.check_call([os.path.join(pkg, "ref_replay"), os.path.join(tiny_model, "gguf_q8_0"), pf, str(prompt.shape[0]), "6", cf, "1"], cwd=pkg)
+    got = np.fromfile(cf, np.int32).reshape(-1, 16)
+    assert np.array_equal(got, oc)
