@@ -254,6 +254,7 @@ struct CodecDecoder::Impl {
     std::vector<int> kv_len; std::vector<long long> n_seen;
     // scratch (shared by streams; one decode at a time)
     DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm; DevBuf<int64_t> d_codes;
+    int64_t* h_codes = nullptr; int ring = 256, ring_idx = 0; // pinned staging ring for the (tiny) code uploads of async calls
     double flops_frame = 0;
 
     static std::vector<float> tensor(const Gguf& g, const std::string& name) {
@@ -459,9 +460,10 @@ CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frame
     m.gu.alloc((size_t)T0 * 2 * m.ffn); m.act.alloc((size_t)T0 * m.ffn);
     m.t1.alloc(max_act); m.t2.alloc(max_act); m.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); m.pcm.alloc((size_t)T);
     m.d_codes.alloc((size_t)T0 * m.n_q);
+    Q3_HIP(hipHostMalloc((void**)&m.h_codes, (size_t)m.ring * T0 * m.n_q * sizeof(int64_t)));
     Q3_HIP(hipDeviceSynchronize());
 }
-CodecDecoder::~CodecDecoder() {}
+CodecDecoder::~CodecDecoder() { if (impl_ && impl_->h_codes) (void)hipHostFree(impl_->h_codes); }
 int CodecDecoder::samples_per_frame() const {
     int s = 1;
     for (int i = 0; i < impl_->n_up; i++) s *= impl_->up_ratios[i];
@@ -482,13 +484,22 @@ void CodecDecoder::reset(int s) {
 }
 
 int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
+    const int T = decode_async(st, s, codes, n_frames, is_last, pcm);
+    Q3_HIP(hipStreamSynchronize(st));
+    return T;
+}
+
+int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
     (void)is_last; // causal stack: nothing is held back (valid_samples == everything)
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
     if (n_frames <= 0) return 0;
     Q3_CHECK(n_frames <= m.max_frames, "too many frames per decode call");
     const int H = m.hidden, T0 = n_frames;
-    Q3_HIP(hipMemcpyAsync(m.d_codes.p, codes, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
+    if (m.ring_idx == m.ring) { Q3_HIP(hipStreamSynchronize(st)); m.ring_idx = 0; } // all earlier uploads have been consumed
+    int64_t* hc = m.h_codes + (size_t)(m.ring_idx++) * m.max_frames * m.n_q;
+    std::copy(codes, codes + (size_t)T0 * m.n_q, hc);
+    Q3_HIP(hipMemcpyAsync(m.d_codes.p, hc, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
     // 1. RVQ sum -> z_ext current rows ; 2. pre_conv
     hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, T0), dim3(256), 0, st, m.d_codes.p, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
                        m.z_ext.cur(s), m.cb_dim);
@@ -578,7 +589,6 @@ int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_fram
     hipLaunchKernelGGL(k_conv_out, dim3((T + 255) / 256), dim3(256), 0, st, m.out_ext.base(s), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.pcm.p, T);
     m.shift(st, m.out_ext, s, T);
     Q3_HIP(hipMemcpyAsync(pcm, m.pcm.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
-    Q3_HIP(hipStreamSynchronize(st));
     return T;
 }
 

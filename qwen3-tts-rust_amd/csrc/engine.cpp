@@ -20,6 +20,7 @@ static double now_ms() {
 Engine::Engine(const EngineParams& p) : p_(p) {
     Q3_CHECK(p.max_batch >= 1 && p.max_batch <= 512, "max_batch out of range");
     Q3_HIP(hipStreamCreate(&st_));
+    Q3_HIP(hipStreamCreate(&st2_));
     const std::string dir = p.model_dir + "/" + quant_dir(p.quant);
     assets_.reset(new HostAssets(dir + "/qwen3_assets.gguf"));
     const int B = p.max_batch;
@@ -80,7 +81,11 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     d_pslotA_.alloc(2 * B); d_pslotA_.upload(slotA.data(), 2 * B);
     d_pposA_.alloc(posA.size()); d_pposA_.upload(posA.data(), posA.size());
     d_tseq_.upload(seq.data(), B);
-    if (p.load_codec) codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", B, 4));
+    if (p.load_codec) {
+        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", B, 4));
+        pcm_pinned_cap_ = (size_t)B * p.max_steps * codec_->samples_per_frame();
+        Q3_HIP(hipHostMalloc((void**)&pcm_pinned_, pcm_pinned_cap_ * sizeof(float)));
+    }
     Q3_HIP(hipStreamSynchronize(st_));
 }
 
@@ -88,6 +93,8 @@ Engine::~Engine() {
     if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
     if (graph_) (void)hipGraphDestroy(graph_);
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
+    if (st2_) (void)hipStreamDestroy(st2_);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -226,21 +233,25 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
     }
     const int spf = codec_ ? codec_->samples_per_frame() : 0;
     std::vector<std::unique_ptr<Chunker>> chunkers;
-    std::vector<bool> first_done(B, false);
+    std::vector<size_t> pcm_len(B, 0);        // samples enqueued so far per sequence (pinned staging area, slot b)
+    std::vector<hipEvent_t> ev_first(B, nullptr);
+    const size_t slot_cap = codec_ ? (size_t)p_.max_steps * spf : 0;
     for (int b = 0; b < B; b++) {
         if (codec_ && want_pcm) codec_->reset(b);
-        chunkers.emplace_back(new Chunker([this, b, &out, spf, want_pcm, &first_done, t0](const int64_t* codes, int n_codes, bool is_final) {
+        chunkers.emplace_back(new Chunker([this, b, spf, want_pcm, &pcm_len, &ev_first, slot_cap](const int64_t* codes, int n_codes, bool is_final) {
             if (!codec_ || !want_pcm) return;
             const int nf = n_codes / 16;
-            const size_t old = out[b].pcm.size();
-            out[b].pcm.resize(old + (size_t)nf * spf);
-            const double c0 = now_ms();
-            const int got = codec_->decode(st_, b, codes, nf, is_final, out[b].pcm.data() + old); // :520
-            stats.codec_ms += now_ms() - c0; stats.codec_calls++;
-            out[b].pcm.resize(old + (size_t)std::max(got, 0));
-            if (!first_done[b]) { first_done[b] = true; out[b].first_chunk_ms = now_ms() - t0; } // first stream_tx.send, :522-523
+            Q3_CHECK(pcm_len[b] + (size_t)nf * spf <= slot_cap, "pcm staging overflow");
+            // engine.rs:520: decode the chunk -- enqueued on the codec stream, overlapping the next AR frames
+            const int got = codec_->decode_async(st2_, b, codes, nf, is_final, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b]);
+            pcm_len[b] += (size_t)std::max(got, 0);
+            stats.codec_calls++;
+            if (!ev_first[b]) { Q3_HIP(hipEventCreate(&ev_first[b])); Q3_HIP(hipEventRecord(ev_first[b], st2_)); } // first stream_tx.send, :522-523
         }));
     }
+    hipEvent_t ev_t0;
+    Q3_HIP(hipEventCreate(&ev_t0));
+    Q3_HIP(hipEventRecord(ev_t0, st2_)); // st2_ is idle here: marks "prefill done" on the codec stream's clock
 
     // ---------------- frame loop ----------------
     code0_given_ = any_sampled;
@@ -294,11 +305,24 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
         }
     }
     talker_->timer = nullptr; predictor_->timer = nullptr;
+    for (int b = 0; b < B; b++) chunkers[b]->push(nullptr, 0, true); // :644
+    {
+        const double c0 = now_ms();
+        Q3_HIP(hipStreamSynchronize(st2_));  // join the decoder (engine.rs:647-649)
+        stats.codec_ms += now_ms() - c0;     // only the part of the codec work the AR loop did not hide
+    }
     for (int b = 0; b < B; b++) {
-        chunkers[b]->push(nullptr, 0, true); // :644
         out[b].n_frames = fed[b];
+        if (want_pcm && codec_) out[b].pcm.assign(pcm_pinned_ + (size_t)b * slot_cap, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b]);
+        if (ev_first[b]) {
+            float ms = 0;
+            Q3_HIP(hipEventElapsedTime(&ms, ev_t0, ev_first[b]));
+            out[b].first_chunk_ms = out[b].prefill_ms + ms;
+            (void)hipEventDestroy(ev_first[b]);
+        }
         out[b].total_ms = now_ms() - t0;
     }
+    (void)hipEventDestroy(ev_t0);
     (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
 }
 
