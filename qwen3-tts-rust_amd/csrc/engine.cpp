@@ -37,6 +37,13 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     for (int o = 0; o < dP_; o++)
         for (int i = 0; i < Q3_EMBD; i++) wt[(size_t)i * dP_ + o] = assets_->proj_w[(size_t)o * Q3_EMBD + i];
     d_proj_wt_.alloc(wt.size()); d_proj_wt_.upload(wt.data(), wt.size());
+    Q3_CHECK(dP_ % 16 == 0, "projection width must be a multiple of 16");
+    {   // blocked copy [dP/16][2048][16] for the per-frame projection of m_hidden
+        std::vector<float> wb((size_t)Q3_EMBD * dP_);
+        for (int o = 0; o < dP_; o++)
+            for (int i = 0; i < Q3_EMBD; i++) wb[((size_t)(o / 16) * Q3_EMBD + i) * 16 + (o % 16)] = assets_->proj_w[(size_t)o * Q3_EMBD + i];
+        d_proj_wblk_.alloc(wb.size()); d_proj_wblk_.upload(wb.data(), wb.size());
+    }
     d_proj_b_.alloc(dP_); d_proj_b_.upload(assets_->proj_b, dP_);
     d_tts_pad_.alloc(Q3_EMBD); d_tts_pad_.upload(assets_->tts_pad(), Q3_EMBD);
     std::vector<const float*> ptrs(16);
@@ -113,7 +120,7 @@ size_t Engine::bytes_per_frame_step(int batch, double mean_ctx) const {
 void Engine::record_frame(int B) {
     const KvCache kvt = kv_t_->view(), kvp = kv_p_->view();
     // :565-573 predictor input = [project(m_hidden) ; project(E_0[code_0])]
-    launch_project_fast(st_, d_thidden_.p, Q3_EMBD, d_proj_wt_.p, d_proj_b_.p, Q3_EMBD, dP_, d_pin_.p, dP_, B);
+    launch_project_blk(st_, d_thidden_.p, Q3_EMBD, d_proj_wblk_.p, d_proj_b_.p, Q3_EMBD, dP_, d_pin_.p, dP_, B);
     launch_gather_rows_keys(st_, d_proj_tab_[0].p, assets_->codec_rows[0], d_keys_.p, 16, dP_, d_pin_.p + (size_t)B * dP_, B);
     {   // :575-582 clear KV (= positions restart at 0) + 2-token prefill; :588-596 only slice q-1 of the 30720 logits is needed
         TokMeta tm{d_pseqA_.p, d_pslotA_.p, d_pposA_.p};

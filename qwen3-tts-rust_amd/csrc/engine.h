@@ -69,7 +69,7 @@ private:
     std::unique_ptr<CodecDecoder> codec_;
     // device assets
     DevBuf<float> d_codec_tab_[16]; DevBuf<float> d_proj_tab_[16];
-    DevBuf<float> d_proj_wt_, d_proj_b_, d_tts_pad_;
+    DevBuf<float> d_proj_wt_, d_proj_wblk_, d_proj_b_, d_tts_pad_;
     DevBuf<const float*> d_tab_ptrs_; DevBuf<int64_t> d_tab_rows_;
     int dP_ = 0;
     // per-sequence device state

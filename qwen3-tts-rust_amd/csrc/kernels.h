@@ -117,6 +117,8 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
                             int ntok);
 void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
                          float* out, int out_stride, int ntok);
+void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk /*[n_out/16][n_in][16]*/, const float* b,
+                        int n_in, int n_out, float* out, int out_stride, int ntok);
 void launch_feedback_keys(hipStream_t st, const float* const* tables, const int64_t* table_rows, const q3_u64* keys, int key_stride,
                           const float* tts_pad, float* out, int ntok);
 void launch_gather_rows_keys(hipStream_t st, const float* table, int64_t rows, const q3_u64* keys, int key_stride, int row_len,

@@ -66,6 +66,67 @@ __device__ __forceinline__ void norm_quant_token(const NormPro& a, int d, int to
     }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Workgroup-cooperative form of the same prologue (identical arithmetic): wave w fetches 256-chunk w (all global
+// loads of the token in ONE round trip instead of a serial chain in a single wave), wave 0 runs the spec's 64-lane
+// sum-of-squares chain over the chunks from LDS, then every wave scales + quantises its own chunk.
+// Requires blockDim.x == 64 * (d/256).  Contains __syncthreads(): all threads of the block must call it.
+// ---------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, bool tok_valid, int lane, int wave, int8_t* xq_dst,
+                                              uint16_t* xd_dst, float* vbuf, float* scal, bool write_global) {
+    const int c = wave; // chunk owned by this wave
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f), g = v;
+    if (tok_valid) {
+        const float* hin = a.h_in;
+        if (a.idx_keys) hin += (size_t)key_code(a.idx_keys[(size_t)tok * a.idx_stride]) * a.h_stride;
+        else hin += (size_t)tok * a.h_stride;
+        v = *reinterpret_cast<const float4*>(hin + 256 * c + 4 * lane);
+        g = *reinterpret_cast<const float4*>(a.g + 256 * c + 4 * lane);
+        if (a.nparts > 0) {
+            const float* pp = a.parts + (size_t)tok * a.parts_stride + 256 * c + 4 * lane;
+            float4 z[4];
+            const int np = a.nparts < 4 ? a.nparts : 4;
+#pragma unroll
+            for (int s = 0; s < 4; s++) if (s < np) z[s] = *reinterpret_cast<const float4*>(pp + (size_t)s * a.parts_slab);
+            float4 y = z[0];
+#pragma unroll
+            for (int s = 1; s < 4; s++) if (s < np) { y.x = y.x + z[s].x; y.y = y.y + z[s].y; y.z = y.z + z[s].z; y.w = y.w + z[s].w; }
+            for (int s = 4; s < a.nparts; s++) {
+                const float4 zz = *reinterpret_cast<const float4*>(pp + (size_t)s * a.parts_slab);
+                y.x = y.x + zz.x; y.y = y.y + zz.y; y.z = y.z + zz.z; y.w = y.w + zz.w;
+            }
+            v.x = v.x + y.x; v.y = v.y + y.y; v.z = v.z + y.z; v.w = v.w + y.w;
+        }
+        if (write_global && a.h_out) *reinterpret_cast<float4*>(a.h_out + (size_t)tok * d + 256 * c + 4 * lane) = v;
+    }
+    *reinterpret_cast<float4*>(vbuf + 256 * c + 4 * lane) = v;
+    __syncthreads();
+    if (wave == 0) {
+        const int nch = d >> 8;
+        float p = 0.0f;
+        for (int cc = 0; cc < nch; cc++) {
+            const float4 u = *reinterpret_cast<const float4*>(vbuf + 256 * cc + 4 * lane);
+            p = q3_fmaf(u.x, u.x, p); p = q3_fmaf(u.y, u.y, p); p = q3_fmaf(u.z, u.z, p); p = q3_fmaf(u.w, u.w, p);
+        }
+        const float ss = wave_sum_bfly(p);
+        const float mean = ss / (float)d;
+        if (lane == 0) scal[0] = 1.0f / q3_sqrtf(mean + a.eps);
+    }
+    __syncthreads();
+    const float scale = scal[0];
+    float4 y;
+    y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
+    if (tok_valid && write_global && a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * d + 256 * c + 4 * lane) = y;
+    float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
+    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    const float dd = amax / 127.0f;
+    const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+    const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
+    const uint32_t pk = (uint32_t)(q0 & 0xFF) | ((uint32_t)(q1 & 0xFF) << 8) | ((uint32_t)(q2 & 0xFF) << 16) | ((uint32_t)(q3v & 0xFF) << 24);
+    *reinterpret_cast<uint32_t*>(xq_dst + 256 * c + 4 * lane) = pk;
+    if ((lane & 7) == 0) xd_dst[8 * c + (lane >> 3)] = f2h(dd);
+}
+
 // ===================================================================================================
 // A: norm prologue + GEMV (K = d <= 2048, one super-segment).  EPI 0: store f32; EPI 1: atomic argmax.
 // ===================================================================================================
@@ -76,7 +137,9 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
     __shared__ float red[8][R * MT];
     __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
     __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    __shared__ __attribute__((aligned(16))) float vbuf_s[2048];
+    __shared__ float scal_s[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
     const int nseg = w.K >> 8, nb = w.K >> 5;
     const int seg = wave; // single super-segment
@@ -90,9 +153,9 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
 #pragma unroll
     for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
     const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
-    for (int m = wave; m < MT; m += nwaves) {
+    for (int m = 0; m < MT; m++) { // (nwaves == K/256 by construction of the launch)
         const int tok = tok0 + m;
-        if (tok < ntok) norm_quant_token(a, w.K, tok, ntok, lane, xq_s[m], xd_s[m], blockIdx.x == 0);
+        norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
     }
     __syncthreads();
     float acc[MT];
@@ -178,7 +241,9 @@ __global__ void __launch_bounds__(512) k_gateup_swiglu(Q8Mat w, int ff, NormPro 
     __shared__ float red[8][2][32 * MT];
     __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
     __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+    __shared__ __attribute__((aligned(16))) float vbuf_s[2048];
+    __shared__ float scal_s[1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
     const int nseg = w.K >> 8, nb = w.K >> 5;
     const int seg = wave;
@@ -191,9 +256,9 @@ __global__ void __launch_bounds__(512) k_gateup_swiglu(Q8Mat w, int ff, NormPro 
     for (int i = 0; i < 8; i++) { wg[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wu[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
     const uint4 dg = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
     const uint4 du = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
-    for (int m = wave; m < MT; m += nwaves) {
+    for (int m = 0; m < MT; m++) {
         const int tok = tok0 + m;
-        if (tok < ntok) norm_quant_token(a, w.K, tok, ntok, lane, xq_s[m], xd_s[m], blockIdx.x == 0);
+        norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
     }
     __syncthreads();
 #pragma unroll
@@ -451,6 +516,36 @@ void launch_project_fast(hipStream_t st, const float* x, int x_stride, const flo
                          float* out, int out_stride, int ntok) {
     hipLaunchKernelGGL(k_project_fast, dim3((n_out + 63) / 64, ntok), dim3(64), n_in * sizeof(float), st, x, x_stride, Wt, b, n_in,
                        n_out, out, out_stride);
+}
+
+// Blocked form: Wblk is [n_out/16][n_in][16] so a workgroup's 16 output columns are one contiguous slab that is
+// staged whole in LDS (n_in*64 B) by all 256 threads; 16 lanes then run the reference-ordered chains from LDS.
+__global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x, int x_stride, const float* __restrict__ Wblk,
+                                                     const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
+                                                     int out_stride) {
+    extern __shared__ __attribute__((aligned(16))) float sm[];
+    float* ws = sm;               // [n_in][16]
+    float* xs = sm + (size_t)n_in * 16;
+    const int ob = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x;
+    const float4* src = reinterpret_cast<const float4*>(Wblk + (size_t)ob * n_in * 16);
+    float4* dst = reinterpret_cast<float4*>(ws);
+    for (int i = tid; i < n_in * 4; i += 256) dst[i] = src[i];
+    for (int i = tid; i < n_in; i += 256) xs[i] = x[(size_t)tok * x_stride + i];
+    __syncthreads();
+    if (tid < 16) {
+        const int o = ob * 16 + tid;
+        float sum = b[o];
+#pragma unroll 16
+        for (int i = 0; i < n_in; i++) { const float t = xs[i] * ws[i * 16 + tid]; sum = sum + t; }
+        out[(size_t)tok * out_stride + o] = sum;
+    }
+}
+void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
+                        float* out, int out_stride, int ntok) {
+    static bool attr_set = false;
+    const size_t lds = (size_t)n_in * 17 * sizeof(float);
+    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    hipLaunchKernelGGL(k_project_blk, dim3(n_out / 16, ntok), dim3(256), lds, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride);
 }
 
 // ===================================================================================================
