@@ -325,6 +325,28 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
     const int grp = n_head / n_kv, kvh = h / grp;
     const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
     const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
+    const int jj = lane >> 4, dc = lane & 15;
+    // ---- latency plan: every global load of the first 256-chunk is issued before the prologue's arithmetic ----
+    // (K/V of cached positions depend only on the page table, not on this token's q/k/v)
+    uint4 kreg[16], vreg[16];
+    {
+        const int jbase = wave * 64;
+        if (jbase < n) {
+            const int page = pt[jbase >> 6];
+            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+#pragma unroll
+            for (int d8 = 0; d8 < 16; d8++) kreg[d8] = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+        }
+#pragma unroll
+        for (int u = 0; u < 16; u++) {
+            const int jg = 16 * u + 4 * wave + jj;
+            vreg[u] = make_uint4(0, 0, 0, 0);
+            if (jg < n && jg != slot) {
+                const int page = pt[jg >> 6];
+                vreg[u] = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
+            }
+        }
+    }
     // ---- prologue: wave 0 = q head, wave 1 = k head, wave 2 = v head ----
     if (wave < 3) {
         const float* vec = qkv + (size_t)tok * qkv_stride + (wave == 0 ? (size_t)h * 128 : wave == 1 ? (size_t)(n_head + kvh) * 128 : (size_t)(n_head + n_kv + kvh) * 128);
@@ -332,18 +354,20 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         const int page = pt[slot >> 6], ps = slot & 63;
         if (wave < 2) {
             const float* wn = wave == 0 ? q_norm_w : k_norm_w;
+            const float w1 = wn[lane], w2 = wn[lane + 64];
+            int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
+            int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+            if (pp < 0) pp = 0;
+            if (pp > n_ctx - 1) pp = n_ctx - 1;
+            const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
             float p = x1 * x1;
             p = q3_fmaf(x2, x2, p);
             const float ss = wave_sum_bfly(p);
             const float mean = ss / 128.0f;
             const float scale = 1.0f / q3_sqrtf(mean + eps);
-            const float y1 = (x1 * scale) * wn[lane], y2 = (x2 * scale) * wn[lane + 64];
-            int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-            int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
-            if (pp < 0) pp = 0;
-            if (pp > n_ctx - 1) pp = n_ctx - 1;
+            const float y1 = (x1 * scale) * w1, y2 = (x2 * scale) * w2;
             float o1, o2;
-            q3_rope_pair(y1, y2, rope_cos[(size_t)pp * 64 + lane], rope_sin[(size_t)pp * 64 + lane], &o1, &o2);
+            q3_rope_pair(y1, y2, cs, sn, &o1, &o2);
             if (wave == 0) { q_s[lane] = o1; q_s[lane + 64] = o2; }
             else {
                 const uint16_t k1 = f2h(o1), k2 = f2h(o2);
@@ -365,7 +389,6 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
     }
     __syncthreads();
     const float scale = 0.08838834764831845f;
-    const int jj = lane >> 4, dc = lane & 15;
     float M = 0.0f, L = 0.0f, O[8];
 #pragma unroll
     for (int i = 0; i < 8; i++) O[i] = 0.0f;
@@ -373,15 +396,30 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         const int jbase = c0 + wave * 64;
         const int jme = jbase + lane;
         const bool valid = jme < n;
+        if (c0 > 0) { // later chunks: load here (the first chunk was prefetched above)
+            if (jbase < n) {
+                const int page = pt[jbase >> 6];
+                const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+#pragma unroll
+                for (int d8 = 0; d8 < 16; d8++) kreg[d8] = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+            }
+#pragma unroll
+            for (int u = 0; u < 16; u++) {
+                const int jg = c0 + 16 * u + 4 * wave + jj;
+                vreg[u] = make_uint4(0, 0, 0, 0);
+                if (jg < n && jg != slot) {
+                    const int page = pt[jg >> 6];
+                    vreg[u] = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
+                }
+            }
+        }
         float s = -INFINITY;
         if (jbase < n) {
-            const int page = pt[jbase >> 6];
-            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
             const bool cur = (jme == slot);
             float acc = 0.0f;
 #pragma unroll
             for (int d8 = 0; d8 < 16; d8++) {
-                uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+                uint4 kk = kreg[d8];
                 if (cur) kk = *reinterpret_cast<const uint4*>(&kcur_s[8 * d8]);
                 const float4 qa = *reinterpret_cast<const float4*>(&q_s[8 * d8]);
                 const float4 qb = *reinterpret_cast<const float4*>(&q_s[8 * d8 + 4]);
@@ -403,20 +441,14 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
 #pragma unroll
         for (int i = 0; i < 8; i++) S[i] = 0.0f;
         const int cn = (n - c0) < 256 ? (n - c0) : 256;
-#pragma unroll 4
+#pragma unroll
         for (int u = 0; u < 16; u++) {
             if (16 * u < cn) {
                 const int jl = 16 * u + 4 * wave + jj;
                 const int jg = c0 + jl;
                 const float pj = p_s[jl];
-                uint4 vv = make_uint4(0, 0, 0, 0);
-                if (jg < n) {
-                    if (jg == slot) vv = *reinterpret_cast<const uint4*>(&vcur_s[dc * 8]);
-                    else {
-                        const int page = pt[jg >> 6];
-                        vv = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
-                    }
-                }
+                uint4 vv = vreg[u];
+                if (jg == slot) vv = *reinterpret_cast<const uint4*>(&vcur_s[dc * 8]);
                 S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
                 S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
                 S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
