@@ -82,6 +82,7 @@ def main():
     ap.add_argument("--model-dir", default=os.environ.get("Q3_BENCH_MODEL", "/tmp/q3tts_synth_full"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--batch", type=int, default=1, help="lock-stepped utterances per GPU (1 = config C2, 64 = config C3)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -108,12 +109,12 @@ def main():
     have_codec = (not args.no_codec) and os.path.exists(codec_path)
     max_frames = 4 * max(args.steps, args.warmup, 2)
     try:
-        eng = Q.Engine(args.model_dir, args.quant, max_batch=1, max_prompt=1024, max_steps=max_frames, load_codec=have_codec,
+        eng = Q.Engine(args.model_dir, args.quant, max_batch=args.batch, max_prompt=1024, max_steps=max_frames, load_codec=have_codec,
                        device=local_rank)
     except Q.Q3Error as ex:
         if have_codec and "codec" in str(ex):
             have_codec = False
-            eng = Q.Engine(args.model_dir, args.quant, max_batch=1, max_prompt=1024, max_steps=max_frames, load_codec=False,
+            eng = Q.Engine(args.model_dir, args.quant, max_batch=args.batch, max_prompt=1024, max_steps=max_frames, load_codec=False,
                            device=local_rank)
         else:
             raise
@@ -129,8 +130,10 @@ def main():
     prompt = build_prompt(eng.assets, spk_emb)
     log("engine up, prompt rows %d" % prompt.shape[0])
 
+    prompts = [prompt] if args.batch == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(args.batch)]
+
     def run(steps, pcm):
-        return eng.generate_batch([prompt], max_steps=4 * steps, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)[0]
+        return eng.generate_batch(prompts, max_steps=4 * steps, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)[0]
 
     if args.warmup > 0:
         run(args.warmup, have_codec)
@@ -153,7 +156,7 @@ def main():
     log("timed region done: %.3f s" % elapsed)
     n_frames = res["codes"].shape[0]
     assert n_frames == 4 * args.steps, "EOS-masked run must emit exactly 4*steps frames"
-    audio_s = n_frames * FRAME_SEC
+    audio_s = n_frames * FRAME_SEC * args.batch
 
     out = None
     if rank == 0:
@@ -170,16 +173,16 @@ def main():
         eng.set_instrument(False)
         si = eng.stats()
         mean_ctx = prompt.shape[0] + n_frames / 2.0
-        step_bytes = eng.bytes_per_step(1, mean_ctx)
+        step_bytes = eng.bytes_per_step(args.batch, mean_ctx)
         gemv_gbs = si["gemv_bytes"] / (si["gemv_ms"] * 1e-3) / 1e9 if si["gemv_ms"] > 0 else 0.0
-        frame_ms = st["frame_loop_ms"] / max(st["frames"], 1)
+        frame_ms = st["frame_loop_ms"] / max(st["frames"] / args.batch, 1)   # one batched step advances every sequence by a frame
         out = {
             "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
             "value": world * audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i8", "data": "synthetic",
-            "config": {"workload": "C2 single utterance per GPU, Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
-                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": 1,
+            "config": {"workload": ("C2 single utterance per GPU" if args.batch == 1 else "C3-style %d lock-stepped utterances per GPU" % args.batch) + ", Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
+                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": args.batch,
                        "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
             "rtf": elapsed / audio_s,
             "first_chunk_ms_p50": statistics.median(lat),
