@@ -14,7 +14,7 @@ namespace q3 {
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 
-enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RES_SCALE = 2, EPI_RES = 3 };
+enum { EPI_NONE = 0, EPI_GELU = 1, EPI_RES_SCALE = 2, EPI_RES = 3, EPI_SNAKE = 4 };
 
 struct GemmArgs {
     const float* A; int lda;        // A rows: time-major activations (extended buffer), row stride lda floats
@@ -24,37 +24,70 @@ struct GemmArgs {
     float* out; int ldo;            // out[m][n]
     int M, N, K;
     int epi; const float* res; int ldr; const float* scale; // EPI_RES_SCALE: out = res + scale[n]*(acc+bias); EPI_RES: res + acc+bias
+    const float *snake_ea, *snake_ib;  // EPI_SNAKE: v + ib[n]*sin^2(v*ea[n]) applied to acc+bias
+    float* ws;                          // split-K partial slabs [z][M][N]
 };
 
+// epilogue shared by all GEMM forms: v = acc (+bias) -> activation / residual -> out
+__device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col) {
+    if (g.bias) v += g.bias[col];
+    if (g.epi == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
+    else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + col] + g.scale[col] * v;
+    else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + col] + v;
+    else if (g.epi == EPI_SNAKE) { const float sn = sinf(v * g.snake_ea[col]); v = v + g.snake_ib[col] * (sn * sn); }
+    return v;
+}
+
 // Workgroup = 4 waves; WM = waves along M.  Tile (32*WM) x (32*(4/WM)), BK = 16, LDS tiles stored k-major so the
-// MFMA fragment reads (lane -> 32 consecutive m or n) are conflict-free.
+// MFMA fragment reads (lane -> 32 consecutive m or n) are conflict-free.  The next K tile is fetched into registers
+// while the current one is multiplied.  gridDim.z > 1 = split-K: each z writes a partial slab (no epilogue) that
+// k_splitk_reduce (or the consumer) sums in slab order.
 template <int WM>
 __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
     constexpr int WN = 4 / WM, BM = 32 * WM, BN = 32 * WN, BK = 16;
+    constexpr int NA = BM * 4 / 256 > 0 ? BM * 4 / 256 : 1, NB = BN * 4 / 256 > 0 ? BN * 4 / 256 : 1;
     __shared__ float As[BK][BM];
     __shared__ float Bs[BK][BN];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave / WN, wn = wave % WN;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    float4 ra[NA], rb[NB];
+    auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
-        // A tile: BM rows x 16 floats; thread -> (row = e % BM, quad = e / BM)
-        for (int e = tid; e < BM * 4; e += 256) {
-            const int r = e % BM, qd = e / BM;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) v = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + r + j * g.dil) * g.lda + ci0 + 4 * qd);
-            As[4 * qd + 0][r] = v.x; As[4 * qd + 1][r] = v.y; As[4 * qd + 2][r] = v.z; As[4 * qd + 3][r] = v.w;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e % BM, qd = e / BM;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < BM * 4 && m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + r + j * g.dil) * g.lda + ci0 + 4 * qd);
         }
-        for (int e = tid; e < BN * 4; e += 256) {
-            const int r = e % BN, qd = e / BN;
-            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (n0 + r < g.N) v = *reinterpret_cast<const float4*>(g.W + (size_t)(n0 + r) * g.K + k0 + 4 * qd);
-            Bs[4 * qd + 0][r] = v.x; Bs[4 * qd + 1][r] = v.y; Bs[4 * qd + 2][r] = v.z; Bs[4 * qd + 3][r] = v.w;
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e % BN, qd = e / BN;
+            rb[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < BN * 4 && n0 + r < g.N) rb[i] = *reinterpret_cast<const float4*>(g.W + (size_t)(n0 + r) * g.K + k0 + 4 * qd);
         }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e % BM, qd = e / BM;
+            if (e < BM * 4) { As[4 * qd + 0][r] = ra[i].x; As[4 * qd + 1][r] = ra[i].y; As[4 * qd + 2][r] = ra[i].z; As[4 * qd + 3][r] = ra[i].w; }
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e % BN, qd = e / BN;
+            if (e < BN * 4) { Bs[4 * qd + 0][r] = rb[i].x; Bs[4 * qd + 1][r] = rb[i].y; Bs[4 * qd + 2][r] = rb[i].z; Bs[4 * qd + 3][r] = rb[i].w; }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stash();
         __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 2) {
             const float a = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
@@ -65,24 +98,96 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < g.N) {
-        const float bv = g.bias ? g.bias[col] : 0.0f;
-        const float sc = (g.epi == EPI_RES_SCALE) ? g.scale[col] : 1.0f;
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < g.M) {
-                float v = acc[r] + bv;
-                if (g.epi == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-                else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + col] + sc * v;
-                else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + col] + v;
-                g.out[(size_t)row * g.ldo + col] = v;
+                if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
+                else g.out[(size_t)row * g.ldo + col] = gemm_epilogue(g, acc[r], row, col);
             }
         }
     }
 }
-static void gemm(hipStream_t st, const GemmArgs& g) {
-    if (g.M <= 32) hipLaunchKernelGGL((k_conv_gemm<1>), dim3((g.N + 127) / 128, (g.M + 31) / 32), dim3(256), 0, st, g);
-    else hipLaunchKernelGGL((k_conv_gemm<2>), dim3((g.N + 63) / 64, (g.M + 63) / 64), dim3(256), 0, st, g);
+__global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= (size_t)g.M * g.N) return;
+    const int row = (int)(i / g.N), col = (int)(i % g.N);
+    float v = g.ws[i];
+    for (int s = 1; s < ksplit; s++) v += g.ws[(size_t)s * g.M * g.N + i];
+    g.out[(size_t)row * g.ldo + col] = gemm_epilogue(g, v, row, col);
+}
+
+// Skinny GEMM for M <= 16 (transformer, ConvNeXt MLPs, conv_in, first transposed conv): weights are streamed exactly
+// once; workgroup = 8 waves = 8 output columns sharing an LDS copy of the A rows; each wave's lanes split K.
+template <int MT>
+__global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
+    constexpr int KT = 512;
+    __shared__ __attribute__((aligned(16))) float As[MT][KT];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int n = blockIdx.x * 8 + wave;
+    const int nn = n < g.N ? n : g.N - 1;
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += KT) {
+        const int kt = (g.K - k0) < KT ? (g.K - k0) : KT;
+        // weights first (independent of the LDS staging)
+        float4 w4[2];
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int kk = 4 * (lane + 64 * i);
+            w4[i] = (kk < kt) ? *reinterpret_cast<const float4*>(g.W + (size_t)nn * g.K + k0 + kk) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
+        __syncthreads(); // previous tile fully consumed
+        for (int e = tid; e < MT * (KT / 4); e += 512) {
+            const int m = e / (KT / 4), kk = 4 * (e % (KT / 4));
+            float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m < g.M && kk < kt) {
+                const int kg = k0 + kk, j = kg / g.cin, ci = kg % g.cin;
+                v = *reinterpret_cast<const float4*>(g.A + (size_t)(m + j * g.dil) * g.lda + ci);
+            }
+            *reinterpret_cast<float4*>(&As[m][kk]) = v;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int kk = 4 * (lane + 64 * i);
+#pragma unroll
+            for (int m = 0; m < MT; m++) {
+                const float4 a = *reinterpret_cast<const float4*>(&As[m][kk]);
+                acc[m] += w4[i].x * a.x + w4[i].y * a.y + w4[i].z * a.z + w4[i].w * a.w;
+            }
+        }
+    }
+    float mine = 0.0f;
+#pragma unroll
+    for (int m = 0; m < MT; m++) {
+        float v = acc[m];
+        for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
+        if (lane == m) mine = v;
+    }
+    if (lane < MT && lane < g.M && n < g.N) g.out[(size_t)lane * g.ldo + n] = gemm_epilogue(g, mine, lane, n);
+}
+static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats) {
+    if (g.M <= 16) {
+        dim3 grid((g.N + 7) / 8);
+        if (g.M <= 4) hipLaunchKernelGGL((k_skinny_gemm<4>), grid, dim3(512), 0, st, g);
+        else if (g.M <= 8) hipLaunchKernelGGL((k_skinny_gemm<8>), grid, dim3(512), 0, st, g);
+        else hipLaunchKernelGGL((k_skinny_gemm<16>), grid, dim3(512), 0, st, g);
+        return;
+    }
+    const bool small = g.M <= 32;
+    const int tiles = small ? ((g.N + 127) / 128) * ((g.M + 31) / 32) : ((g.N + 63) / 64) * ((g.M + 63) / 64);
+    int ksplit = 1;
+    while (tiles * ksplit < 256 && ksplit < 16 && (g.K / (ksplit * 2)) % 16 == 0 && g.K / (ksplit * 2) >= 128 &&
+           (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
+    g.ws = ws;
+    if (small) hipLaunchKernelGGL((k_conv_gemm<1>), dim3((g.N + 127) / 128, (g.M + 31) / 32, ksplit), dim3(256), 0, st, g);
+    else hipLaunchKernelGGL((k_conv_gemm<2>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ksplit), dim3(256), 0, st, g);
+    if (ksplit > 1) {
+        const size_t n = (size_t)g.M * g.N;
+        hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ksplit);
+    }
 }
 
 // ---------------- small elementwise / reduction kernels ----------------
@@ -253,7 +358,7 @@ struct CodecDecoder::Impl {
     std::vector<std::vector<DevBuf<float>>> kbuf, vbuf; // [stream][layer]
     std::vector<int> kv_len; std::vector<long long> n_seen;
     // scratch (shared by streams; one decode at a time)
-    DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm; DevBuf<int64_t> d_codes;
+    DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm, splitk_ws; DevBuf<int64_t> d_codes;
     int64_t* h_codes = nullptr; int ring = 256, ring_idx = 0; // pinned staging ring for the (tiny) code uploads of async calls
     double flops_frame = 0;
 
@@ -307,11 +412,12 @@ struct CodecDecoder::Impl {
         for (auto& b : e.buf) { b.alloc((size_t)(H + Tmax) * C); b.zero(); }
     }
     void run_conv(hipStream_t st, const ConvW& c, const float* A, int lda, int M, float* out, int ldo, int epi = EPI_NONE,
-                  const float* res = nullptr, int ldr = 0, const float* scale = nullptr) {
+                  const float* res = nullptr, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr) {
         GemmArgs g{};
         g.A = A; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out; g.ldo = ldo;
         g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res; g.ldr = ldr; g.scale = scale;
-        gemm(st, g);
+        if (sn) { g.snake_ea = sn->ea.p; g.snake_ib = sn->inv_eb.p; }
+        gemm(st, g, splitk_ws.p, splitk_ws.n);
     }
     // move the last H rows of an extended buffer (rows [T, T+H)) to its front
     void shift(hipStream_t st, Ext& e, int s, int T) {
@@ -460,6 +566,7 @@ CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frame
     m.gu.alloc((size_t)T0 * 2 * m.ffn); m.act.alloc((size_t)T0 * m.ffn);
     m.t1.alloc(max_act); m.t2.alloc(max_act); m.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); m.pcm.alloc((size_t)T);
     m.d_codes.alloc((size_t)T0 * m.n_q);
+    m.splitk_ws.alloc(std::max<size_t>(max_act * 4, (size_t)1 << 20));
     Q3_HIP(hipHostMalloc((void**)&m.h_codes, (size_t)m.ring * T0 * m.n_q * sizeof(int64_t)));
     Q3_HIP(hipDeviceSynchronize());
 }
@@ -577,9 +684,8 @@ int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int 
             auto& R = B.ru[u];
             m.snake(st, R.s1, y, re.cur(s), T);
             float* c1o = d; // the block input buffer is free now: reuse as scratch [T][co]
-            m.run_conv(st, R.c1, re.base(s), B.cout, T, c1o, B.cout);
+            m.run_conv(st, R.c1, re.base(s), B.cout, T, c1o, B.cout, EPI_SNAKE, nullptr, 0, nullptr, &R.s2); // conv1 + snake2 fused
             m.shift(st, re, s, T);
-            m.snake(st, R.s2, c1o, c1o, T);
             m.run_conv(st, R.c2, c1o, B.cout, T, y, B.cout, EPI_RES, y, B.cout);
         }
         d = y;
