@@ -44,6 +44,7 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
 struct NormArgs {
     const float* h_in; int h_stride;            // [ntok][h_stride]
     const int32_t* idx; int idx_stride;         // optional: h row = h_in + idx[tok*idx_stride]*h_stride
+    const unsigned long long* idx_keys;         // optional: same, row selected by an argmax key (low word = ~index)
     const float* parts; int nparts; int parts_stride; // [p][ntok][parts_stride]
     float* h_out;                               // optional [ntok][d]
     const float* g; float eps; int d;
@@ -80,6 +81,8 @@ void launch_project_table(hipStream_t st, const float* table, int64_t rows, cons
 void launch_feedback(hipStream_t st, const float* const* tables /*device [16]*/, const int64_t* table_rows /*device[16]*/,
                      const int32_t* codes, int codes_stride, const float* tts_pad, float* out, int ntok);
 
+void launch_argmax_keys(hipStream_t st, const float* logits, int stride, int n, const int32_t* mask_per_tok, unsigned long long* keys,
+                        int key_stride, int ntok);
 void launch_gather_rows(hipStream_t st, const float* table, int64_t rows, const int32_t* idx, int idx_stride, int row_len,
                         float* dst, int ntok);
 

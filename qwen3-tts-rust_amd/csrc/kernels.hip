@@ -79,6 +79,11 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
     }
 }
 
+__global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                              float* __restrict__ out, int out_stride, int ntok);
+__global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                               float* __restrict__ out, int out_stride, int ntok);
+
 template <int LPR, int MT>
 static void gemv_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
                         float* out, int out_stride, int ntok) {
@@ -99,6 +104,21 @@ static void gemv_launch_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, 
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
                     float* out, int out_stride, int ntok, int lpr_hint) {
     const int nsseg = ((w.K >> 8) + 7) / 8;
+    if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
+        const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
+        hipLaunchKernelGGL(k_gemm_q8_mfma, dim3((nrows + 31) / 32, nsseg, (ntok + 31) / 32), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                           out_stride, ntok);
+        return;
+    }
+    if (ntok > 8 && !lpr_hint) {
+        const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
+        static bool attr_set = false;
+        const size_t lds = 16 * 2048 + 16 * 128 + 8 * 16 * 64 * 4; // 66 KiB: activations of 16 tokens + segment sums
+        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        hipLaunchKernelGGL(k_gemm_q8_tok, dim3((nrows + 63) / 64, nsseg, (ntok + 15) / 16), dim3(64 * nw), lds, st, w, row0, nrows, xq, xd, out,
+                           out_stride, ntok);
+        return;
+    }
     int lpr = lpr_hint;
     if (!lpr) { // enough workgroups to cover 256 CUs twice, else narrower row groups
         if ((long)(nrows / 32) * nsseg >= 512) lpr = 2;
@@ -111,6 +131,151 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
 }
 
 // =====================================================================================================
+// Batched-step form (ntok > 8): weight-stationary.  A wave keeps its 32 rows x 256-element segment of weights in
+// registers (8 x 16 B per lane) and sweeps up to 32 tokens, so weights are read once per 32 tokens instead of once
+// per 8; per (row, token) the arithmetic is the same block chain, and segments are combined in order through LDS.
+// =====================================================================================================
+__global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
+                                                     const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
+                                                     int ntok) {
+    // lane = row (64 rows per wave: two 32-row groups), wave = segment: no cross-lane traffic in the token sweep
+    constexpr int TT = 16;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    int8_t* xq_s = reinterpret_cast<int8_t*>(smem);                                   // [TT][2048]
+    uint16_t* xd_s = reinterpret_cast<uint16_t*>(smem + TT * 2048);                   // [TT][64]
+    float* red = reinterpret_cast<float*>(smem + TT * 2048 + TT * 128);               // [8][TT][64]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    const int tok0 = blockIdx.z * TT;
+    int nsg = nseg - sseg * 8;
+    if (nsg > 8) nsg = 8;
+    const int kspan = nsg * 256;
+    const int nt = (ntok - tok0) < TT ? (ntok - tok0) : TT;
+    const bool active = seg < nseg;
+    uint4 wlo[8], whi[8];
+    float dwf[8];
+    if (active) {
+        int row = row0 + blockIdx.x * 64 + lane;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + r32 * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            wlo[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * 1024);
+            whi[i] = *reinterpret_cast<const uint4*>(base + (size_t)i * 1024 + 512);
+        }
+        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+#pragma unroll
+        for (int i = 0; i < 8; i++) dwf[i] = h2f(half_of(dwv, i));
+    }
+    for (int e = threadIdx.x; e < nt * (kspan / 16); e += blockDim.x) {
+        const int m = e / (kspan / 16), c = e % (kspan / 16);
+        *reinterpret_cast<uint4*>(xq_s + m * 2048 + c * 16) =
+            *reinterpret_cast<const uint4*>(xq + (size_t)(tok0 + m) * w.K + sseg * 2048 + c * 16);
+    }
+    for (int e = threadIdx.x; e < nt * nsg; e += blockDim.x) {
+        const int m = e / nsg, c = e % nsg;
+        *reinterpret_cast<uint4*>(xd_s + m * 64 + c * 8) = *reinterpret_cast<const uint4*>(xd + (size_t)(tok0 + m) * nb + (sseg * 8 + c) * 8);
+    }
+    __syncthreads();
+    if (active) {
+        for (int m = 0; m < nt; m++) {
+            const int8_t* xp = xq_s + m * 2048 + wave * 256;
+            const uint4 dxv = *reinterpret_cast<const uint4*>(xd_s + m * 64 + wave * 8);
+            float acc = 0.0f;
+#pragma unroll
+            for (int i = 0; i < 8; i++) {
+                const uint4 xa = *reinterpret_cast<const uint4*>(xp + i * 32);       // wave-uniform address: LDS broadcast
+                const uint4 xb = *reinterpret_cast<const uint4*>(xp + i * 32 + 16);
+                const int isum = dot16(wlo[i], xa) + dot16(whi[i], xb);
+                const float sc = dwf[i] * h2f(half_of(dxv, i));
+                acc = q3_fmaf((float)isum, sc, acc);
+            }
+            red[(wave * TT + m) * 64 + lane] = acc;
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < nt * 64; t += blockDim.x) {
+        const int m = t >> 6, rr = t & 63;
+        float S = red[(0 * TT + m) * 64 + rr];
+        for (int s = 1; s < nsg; s++) S = S + red[(s * TT + m) * 64 + rr];
+        const int orow = blockIdx.x * 64 + rr, tok = tok0 + m;
+        if (orow < nrows) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+    }
+}
+
+// =====================================================================================================
+// Batched-step / prefill form on the matrix cores (ntok >= 16): v_mfma_i32_32x32x32_i8 computes, for one 32-block of
+// K, the EXACT integer dots of 32 tokens x 32 rows; the per-block f32 scale + fma chain of spec S3 then runs on the
+// 16 accumulator values each lane owns.  B operand = a weight tile exactly as stored (lane = half*32 + row), A operand
+// = 16 activation bytes of token (lane & 31), half (lane >> 5).  Wave = segment, workgroup = super-segment.
+// =====================================================================================================
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
+                                                      const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
+                                                      int ntok) {
+    __shared__ float red[8][32][33];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    const int tok0 = blockIdx.z * 32;
+    int nsg = nseg - sseg * 8;
+    if (nsg > 8) nsg = 8;
+    if (seg < nseg) {
+        int row = row0 + blockIdx.x * 32 + r;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+        i32x4v wv[8], av[8];
+#pragma unroll
+        for (int i = 0; i < 8; i++) wv[i] = *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
+        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+        int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
+        if (atok > ntok - 1) atok = ntok - 1;
+        const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + i * 32);
+        // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
+        uint4 dxv[16];
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            int t = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            if (t > ntok - 1) t = ntok - 1;
+            dxv[g] = *reinterpret_cast<const uint4*>(xd + (size_t)t * nb + seg * 8);
+        }
+        float acc[16];
+#pragma unroll
+        for (int g = 0; g < 16; g++) acc[g] = 0.0f;
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            i32x16 c;
+#pragma unroll
+            for (int g = 0; g < 16; g++) c[g] = 0;
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
+            const float dwf = h2f(half_of(dwv, i));
+#pragma unroll
+            for (int g = 0; g < 16; g++) {
+                const float sc = dwf * h2f(half_of(dxv[g], i));
+                acc[g] = q3_fmaf((float)c[g], sc, acc[g]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) {
+        const int m = t >> 5, rr = t & 31;
+        float S = red[0][m][rr];
+        for (int s = 1; s < nsg; s++) S = S + red[s][m][rr];
+        const int orow = blockIdx.x * 32 + rr, tok = tok0 + m;
+        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+    }
+}
+
+// =====================================================================================================
 // residual + RMSNorm + int8 activation quantisation (spec S4, S2, S9).  One wave per token: lane l owns
 // elements 256c+4l..+3 of every 256-chunk; fma chain in index order; xor butterfly.
 // =====================================================================================================
@@ -118,7 +283,8 @@ __global__ void __launch_bounds__(64) k_rmsnorm_quant(NormArgs a) {
     const int tok = blockIdx.x, lane = threadIdx.x;
     const int nch = a.d >> 8;
     const float* hin = a.h_in;
-    if (a.idx) hin += (size_t)a.idx[(size_t)tok * a.idx_stride] * a.h_stride;
+    if (a.idx_keys) hin += (size_t)key_code(a.idx_keys[(size_t)tok * a.idx_stride]) * a.h_stride;
+    else if (a.idx) hin += (size_t)a.idx[(size_t)tok * a.idx_stride] * a.h_stride;
     else hin += (size_t)tok * a.h_stride;
     float4 x[8];
     float p = 0.0f;
@@ -488,6 +654,27 @@ __global__ void __launch_bounds__(256) k_feedback(const float* const* __restrict
 void launch_feedback(hipStream_t st, const float* const* tables, const int64_t* table_rows, const int32_t* codes,
                      int codes_stride, const float* tts_pad, float* out, int ntok) {
     hipLaunchKernelGGL(k_feedback, dim3(8, ntok), dim3(256), 0, st, tables, table_rows, codes, codes_stride, tts_pad, out);
+}
+
+// argmax over stored logits -> argmax key (batched-step path; same first-max semantics as the fused epilogue)
+__global__ void __launch_bounds__(256) k_argmax_keys(const float* __restrict__ logits, int stride, int n, const int32_t* __restrict__ mask_per_tok,
+                                                     unsigned long long* __restrict__ keys, int key_stride) {
+    __shared__ unsigned long long best[256];
+    const int tok = blockIdx.x, t = threadIdx.x;
+    const int mk = mask_per_tok ? mask_per_tok[tok] : -1;
+    unsigned long long k = pack_key(-INFINITY, 0);
+    for (int i = t; i < n; i += 256) {
+        const float v = logits[(size_t)tok * stride + i];
+        if (i != mk && v > -INFINITY) { const unsigned long long c = pack_key(v, i); k = c > k ? c : k; }
+    }
+    best[t] = k;
+    __syncthreads();
+    for (int s = 128; s >= 1; s >>= 1) { if (t < s && best[t + s] > best[t]) best[t] = best[t + s]; __syncthreads(); }
+    if (t == 0) keys[(size_t)tok * key_stride] = best[0];
+}
+void launch_argmax_keys(hipStream_t st, const float* logits, int stride, int n, const int32_t* mask_per_tok, unsigned long long* keys,
+                        int key_stride, int ntok) {
+    hipLaunchKernelGGL(k_argmax_keys, dim3(ntok), dim3(256), 0, st, logits, stride, n, mask_per_tok, keys, key_stride);
 }
 
 // row gather: dst[tok][:] = table[max(idx,0)][:]  (pre-projected codec rows -> predictor input)

@@ -35,11 +35,11 @@ public:
             TokMeta tm{d_seq_.p, d_slot_.p, d_pos_.p};
             Transformer::Input in; in.x = d_x_.p; in.x_stride = hp.n_embd;
             model_->set_same_seq_tokens(true);
-            model_->forward(st_, in, n, tm, kv_->view(), model_->fused ? nullptr : d_hid_.p);
+            model_->forward(st_, in, n, tm, kv_->view(), nullptr);
             const bool want_logits = logits_out && row1 > row0;
             const int r0 = row0 & ~31, nr = want_logits ? row1 - r0 : 0;
             if (want_logits && d_logits_.n < (size_t)n * nr) d_logits_.alloc((size_t)n * nr);
-            if (want_logits || model_->fused) model_->head(st_, 0, n, want_logits ? r0 : 0, nr, d_logits_.p, nr, nullptr, -1, d_hid_.p);
+            model_->head(st_, 0, n, want_logits ? r0 : 0, nr, d_logits_.p, nr, nullptr, -1, d_hid_.p);
             Q3_HIP(hipStreamSynchronize(st_));
             if (want_logits) {
                 std::vector<float> tmp((size_t)n * nr);

@@ -133,7 +133,7 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     d_mrope_.alloc(4); d_mrope_.upload(hp_.mrope_sec, 4);
     nparts_d_ = ((ff >> 8) + 7) / 8;
     const size_t T = (size_t)max_tok;
-    scratch_.alloc(T * 32);
+    scratch_.alloc(T * 32); hid_.alloc(T * d); big_logits_.alloc(T * 2176);
     h_.alloc(T * d); h2_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
     qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
     const size_t mx = (size_t)(d > dq ? d : dq);
@@ -150,8 +150,9 @@ void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, cons
 void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
     Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
-    last_fused_ = fused; last_ntok_ = ntok;
-    if (fused) {
+    const bool use_fused = fused && ntok <= 8; // batched steps (ntok > 8) take the weight-stationary token-sweep GEMM path
+    last_fused_ = use_fused; last_ntok_ = ntok;
+    if (use_fused) {
         // residual stream ping-pongs h_ <-> h2_: a fused prologue may not overwrite what other workgroups still read
         for (int l = 0; l < hp_.n_layer; l++) {
             const Layer& L = layers_[l];
@@ -186,7 +187,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     for (int l = 0; l < hp_.n_layer; l++) {
         const Layer& L = layers_[l];
         NormArgs a{};
-        if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx = in.idx; a.idx_stride = in.idx_stride; a.nparts = 0; }
+        if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx = in.idx; a.idx_keys = in.idx_keys; a.idx_stride = in.idx_stride; a.nparts = 0; }
         else { a.h_in = h_.p; a.h_stride = d; a.parts = parts_d_.p; a.nparts = nparts_d_; a.parts_stride = d; }
         a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p;
         launch_rmsnorm_quant(st, a, ntok);
@@ -205,7 +206,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     }
     NormArgs f{};
     f.h_in = h_.p; f.h_stride = d; f.parts = parts_d_.p; f.nparts = nparts_d_; f.parts_stride = d; f.h_out = nullptr;
-    f.g = output_norm_; f.eps = hp_.eps; f.d = d; f.xq = xq_.p; f.xd = xd_.p; f.xn_out = hidden_out;
+    f.g = output_norm_; f.eps = hp_.eps; f.d = d; f.xq = xq_.p; f.xd = xd_.p; f.xn_out = hidden_out ? hidden_out : hid_.p;
     launch_rmsnorm_quant(st, f, ntok);
 }
 
@@ -232,7 +233,15 @@ void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nr
         if (timer) timer->end(st, (double)nrows * ((double)d * 1.0625));
         return;
     }
-    Q3_CHECK(am == nullptr, "argmax epilogue needs the fused path");
+    if (hidden_out) launch_copy_f32(st, hid_.p + (size_t)tok0 * d, hidden_out, (size_t)tok_count * d);
+    if (nrows <= 0) return;
+    if (am) { // batched-step path: logits to scratch, then argmax keys
+        const int nv = nrows_valid > 0 ? nrows_valid : nrows;
+        if (big_logits_.n < (size_t)tok_count * nrows) throw Error("head scratch too small");
+        gemv(st, output_, row0, nrows, xq_.p + (size_t)tok0 * d, xd_.p + (size_t)tok0 * (d / 32), big_logits_.p, nrows, tok_count);
+        launch_argmax_keys(st, big_logits_.p, nrows, nv, am->mask_per_tok, am->keys, am->key_stride, tok_count);
+        return;
+    }
     gemv(st, output_, row0, nrows, xq_.p + (size_t)tok0 * d, xd_.p + (size_t)tok0 * (d / 32), logits, logits_stride, tok_count);
 }
 

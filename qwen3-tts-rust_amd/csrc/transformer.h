@@ -49,7 +49,7 @@ public:
 private:
     struct Layer { Q8Mat wqkv, wo, wgu, wdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
     float* scratch_logits(int) { return scratch_.p; }
-    DevBuf<float> scratch_;
+    DevBuf<float> scratch_, hid_, big_logits_;
     void gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
               int out_stride, int ntok);
     Q8Mat make_mat(int N, int K);

@@ -29,7 +29,8 @@ def _bits(a):
     return np.ascontiguousarray(a, np.float32).view(np.uint32)
 
 
-@pytest.mark.parametrize("n,k,ntok", [(32, 256, 1), (96, 2048, 1), (4096, 2048, 1), (256, 6144, 3), (2048, 1024, 2), (160, 3072, 9), (40, 512, 5)])
+@pytest.mark.parametrize("n,k,ntok", [(32, 256, 1), (96, 2048, 1), (4096, 2048, 1), (256, 6144, 3), (2048, 1024, 2), (160, 3072, 9), (40, 512, 5),
+                                      (96, 2048, 16), (200, 6144, 33), (64, 1024, 70), (2176, 2048, 43), (33, 256, 12)])  # ntok>=16: int8 MFMA path; 9..15: token sweep
 def test_gemv_q8_bit_exact(gpu, oracle, n, k, ntok):
     rng = np.random.default_rng(n + k)
     raw = _q8_encode((rng.standard_normal((n, k)) * 0.02).astype(np.float32))
