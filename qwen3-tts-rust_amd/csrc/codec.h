@@ -9,14 +9,16 @@ namespace q3 {
 
 class CodecDecoder {
 public:
-    CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call);
+    // n_lanes: independent scratch sets so that decodes of different streams can run concurrently on different HIP streams
+    CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call, int n_lanes = 1);
+    int n_lanes() const;
     ~CodecDecoder();
     int samples_per_frame() const;
     void reset(int stream); // AudioDecoder::create_state (onnx.rs:338-340, 474-495)
     // codes: host [n_frames][16] (already clamped to [0,2047], engine.rs:515-519); pcm: host, n_frames*spf floats
     int decode(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm);
     // same, but returns right after enqueueing: pcm_pinned must be hipHostMalloc'd and stay valid until `st` is synchronised
-    int decode_async(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm_pinned);
+    int decode_async(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm_pinned, int lane = 0);
     double flops_per_frame() const;
 private:
     struct Impl;

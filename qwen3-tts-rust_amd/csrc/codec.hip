@@ -358,8 +358,11 @@ struct CodecDecoder::Impl {
     std::vector<std::vector<DevBuf<float>>> kbuf, vbuf; // [stream][layer]
     std::vector<int> kv_len; std::vector<long long> n_seen;
     // scratch (shared by streams; one decode at a time)
-    DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm, splitk_ws; DevBuf<int64_t> d_codes;
-    int64_t* h_codes = nullptr; int ring = 256, ring_idx = 0; // pinned staging ring for the (tiny) code uploads of async calls
+    struct Scratch { // one set per concurrency lane: independent decodes run on different HIP streams at the same time
+        DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm, splitk_ws; DevBuf<int64_t> d_codes;
+        int64_t* h_codes = nullptr; int ring_idx = 0; // pinned staging ring for the (tiny) code uploads of async calls
+    };
+    std::vector<Scratch> lanes; Scratch* S = nullptr; int ring = 256;
     double flops_frame = 0;
 
     static std::vector<float> tensor(const Gguf& g, const std::string& name) {
@@ -417,7 +420,7 @@ struct CodecDecoder::Impl {
         g.A = A; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out; g.ldo = ldo;
         g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res; g.ldr = ldr; g.scale = scale;
         if (sn) { g.snake_ea = sn->ea.p; g.snake_ib = sn->inv_eb.p; }
-        gemm(st, g, splitk_ws.p, splitk_ws.n);
+        gemm(st, g, S->splitk_ws.p, S->splitk_ws.n);
     }
     // move the last H rows of an extended buffer (rows [T, T+H)) to its front
     void shift(hipStream_t st, Ext& e, int s, int T) {
@@ -426,8 +429,8 @@ struct CodecDecoder::Impl {
         float* b = e.base(s);
         if (T >= e.H) hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, b, n);
         else {
-            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, tmp_hist.p, n);
-            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, tmp_hist.p, b, n);
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, S->tmp_hist.p, n);
+            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S->tmp_hist.p, b, n);
         }
     }
     void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int T) {
@@ -436,7 +439,7 @@ struct CodecDecoder::Impl {
     }
 };
 
-CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames) : impl_(new Impl()) {
+CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes) : impl_(new Impl()) {
     Impl& m = *impl_;
     Gguf g(path);
     m.n_streams = n_streams; m.max_frames = max_frames;
@@ -562,15 +565,20 @@ CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frame
         for (int l = 0; l < m.n_layers; l++) { m.kbuf[s][l].alloc((size_t)(m.window + T0) * H); m.vbuf[s][l].alloc((size_t)(m.window + T0) * H); m.kbuf[s][l].zero(); m.vbuf[s][l].zero(); }
     }
     m.kv_len.assign(n_streams, 0); m.n_seen.assign(n_streams, 0);
-    m.h.alloc((size_t)T0 * H); m.xn.alloc((size_t)T0 * H); m.qkv.alloc((size_t)T0 * 3 * H); m.att.alloc((size_t)T0 * H);
-    m.gu.alloc((size_t)T0 * 2 * m.ffn); m.act.alloc((size_t)T0 * m.ffn);
-    m.t1.alloc(max_act); m.t2.alloc(max_act); m.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); m.pcm.alloc((size_t)T);
-    m.d_codes.alloc((size_t)T0 * m.n_q);
-    m.splitk_ws.alloc(std::max<size_t>(max_act * 4, (size_t)1 << 20));
-    Q3_HIP(hipHostMalloc((void**)&m.h_codes, (size_t)m.ring * T0 * m.n_q * sizeof(int64_t)));
+    m.lanes.resize(n_lanes > 0 ? n_lanes : 1);
+    for (auto& L : m.lanes) {
+        L.h.alloc((size_t)T0 * H); L.xn.alloc((size_t)T0 * H); L.qkv.alloc((size_t)T0 * 3 * H); L.att.alloc((size_t)T0 * H);
+        L.gu.alloc((size_t)T0 * 2 * m.ffn); L.act.alloc((size_t)T0 * m.ffn);
+        L.t1.alloc(max_act); L.t2.alloc(max_act); L.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); L.pcm.alloc((size_t)T);
+        L.d_codes.alloc((size_t)T0 * m.n_q);
+        L.splitk_ws.alloc(std::max<size_t>(max_act * 4, (size_t)1 << 20));
+        Q3_HIP(hipHostMalloc((void**)&L.h_codes, (size_t)m.ring * T0 * m.n_q * sizeof(int64_t)));
+    }
+    m.S = &m.lanes[0];
     Q3_HIP(hipDeviceSynchronize());
 }
-CodecDecoder::~CodecDecoder() { if (impl_ && impl_->h_codes) (void)hipHostFree(impl_->h_codes); }
+CodecDecoder::~CodecDecoder() { if (impl_) for (auto& L : impl_->lanes) if (L.h_codes) (void)hipHostFree(L.h_codes); }
+int CodecDecoder::n_lanes() const { return (int)impl_->lanes.size(); }
 int CodecDecoder::samples_per_frame() const {
     int s = 1;
     for (int i = 0; i < impl_->n_up; i++) s *= impl_->up_ratios[i];
@@ -591,50 +599,54 @@ void CodecDecoder::reset(int s) {
 }
 
 int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
-    const int T = decode_async(st, s, codes, n_frames, is_last, pcm);
+    const int T = decode_async(st, s, codes, n_frames, is_last, pcm, 0);
     Q3_HIP(hipStreamSynchronize(st));
     return T;
 }
 
-int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
+int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm, int lane) {
     (void)is_last; // causal stack: nothing is held back (valid_samples == everything)
-    Impl& m = *impl_;
+    Impl& mm = *impl_;
+    Q3_CHECK(lane >= 0 && lane < (int)mm.lanes.size(), "codec lane out of range");
+    mm.S = &mm.lanes[lane];
+    struct View : Impl::Scratch {}; // scratch members are reached through m.S below
+    Impl& m = mm;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
     if (n_frames <= 0) return 0;
     Q3_CHECK(n_frames <= m.max_frames, "too many frames per decode call");
     const int H = m.hidden, T0 = n_frames;
-    if (m.ring_idx == m.ring) { Q3_HIP(hipStreamSynchronize(st)); m.ring_idx = 0; } // all earlier uploads have been consumed
-    int64_t* hc = m.h_codes + (size_t)(m.ring_idx++) * m.max_frames * m.n_q;
+    if (m.S->ring_idx == m.ring) { Q3_HIP(hipStreamSynchronize(st)); m.S->ring_idx = 0; } // all earlier uploads have been consumed
+    int64_t* hc = m.S->h_codes + (size_t)(m.S->ring_idx++) * m.max_frames * m.n_q;
     std::copy(codes, codes + (size_t)T0 * m.n_q, hc);
-    Q3_HIP(hipMemcpyAsync(m.d_codes.p, hc, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
+    Q3_HIP(hipMemcpyAsync(m.S->d_codes.p, hc, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
     // 1. RVQ sum -> z_ext current rows ; 2. pre_conv
-    hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, T0), dim3(256), 0, st, m.d_codes.p, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
+    hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, T0), dim3(256), 0, st, m.S->d_codes.p, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
                        m.z_ext.cur(s), m.cb_dim);
-    m.run_conv(st, m.pre_conv, m.z_ext.base(s), m.cb_dim, T0, m.h.p, H);
+    m.run_conv(st, m.pre_conv, m.z_ext.base(s), m.cb_dim, T0, m.S->h.p, H);
     m.shift(st, m.z_ext, s, T0);
     // 3. transformer
     const int kvl = m.kv_len[s];
     for (int l = 0; l < m.n_layers; l++) {
         auto& L = m.tf[l];
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, L.attn_norm.p, H, m.eps, m.xn.p, H);
-        m.run_conv(st, L.wqkv, m.xn.p, H, T0, m.qkv.p, 3 * H);
-        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, T0), dim3(256), 0, st, m.qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, L.attn_norm.p, H, m.eps, m.S->xn.p, H);
+        m.run_conv(st, L.wqkv, m.S->xn.p, H, T0, m.S->qkv.p, 3 * H);
+        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, T0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
                            m.n_seen[s], m.max_pos);
-        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, T0), dim3(256), 0, st, m.qkv.p, 3 * H, H, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl);
-        hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, T0), dim3(64), 0, st, m.qkv.p, 3 * H, H, m.head_dim, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl,
-                           m.window, m.att.p, H);
-        m.run_conv(st, L.wo, m.att.p, H, T0, m.h.p, H, EPI_RES_SCALE, m.h.p, H, L.ls_attn.p);
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, L.ffn_norm.p, H, m.eps, m.xn.p, H);
-        m.run_conv(st, L.wgu, m.xn.p, H, T0, m.gu.p, 2 * m.ffn);
-        hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, T0), dim3(256), 0, st, m.gu.p, m.ffn, m.act.p);
-        m.run_conv(st, L.wdown, m.act.p, m.ffn, T0, m.h.p, H, EPI_RES_SCALE, m.h.p, H, L.ls_ffn.p);
+        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, T0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl);
+        hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, T0), dim3(64), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl,
+                           m.window, m.S->att.p, H);
+        m.run_conv(st, L.wo, m.S->att.p, H, T0, m.S->h.p, H, EPI_RES_SCALE, m.S->h.p, H, L.ls_attn.p);
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, L.ffn_norm.p, H, m.eps, m.S->xn.p, H);
+        m.run_conv(st, L.wgu, m.S->xn.p, H, T0, m.S->gu.p, 2 * m.ffn);
+        hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, T0), dim3(256), 0, st, m.S->gu.p, m.ffn, m.S->act.p);
+        m.run_conv(st, L.wdown, m.S->act.p, m.ffn, T0, m.S->h.p, H, EPI_RES_SCALE, m.S->h.p, H, L.ls_ffn.p);
         // keep the last window-1 positions as history
         const int tot = kvl + T0, keep = tot < m.window - 1 ? tot : m.window - 1;
         if (tot > keep) {
             const size_t n = (size_t)keep * H;
             for (DevBuf<float>* b : {&m.kbuf[s][l], &m.vbuf[s][l]}) {
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->p + (size_t)(tot - keep) * H, m.tmp_hist.p, n);
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.tmp_hist.p, b->p, n);
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->p + (size_t)(tot - keep) * H, m.S->tmp_hist.p, n);
+                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.S->tmp_hist.p, b->p, n);
             }
         }
     }
@@ -644,38 +656,38 @@ int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int 
         m.n_seen[s] += T0;
     }
     // 4. final norm -> t1 [T0][H]
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.h.p, H, m.tf_norm.p, H, m.eps, m.t1.p, H);
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, m.tf_norm.p, H, m.eps, m.S->t1.p, H);
     // 5. upsample stages: x in t1
     int T = T0;
-    float* x = m.t1.p;
+    float* x = m.S->t1.p;
     for (int i = 0; i < m.n_up; i++) {
         auto& U = m.up[i];
         const int f = m.up_ratios[i];
         Ext& e = m.dw_ext[i];
         m.run_conv(st, U.ct, x, H, T, e.cur(s), f * H); // [T][f*H] == [T*f][H]
         T *= f;
-        hipLaunchKernelGGL(k_dwconv7, dim3((H + 255) / 256, T), dim3(256), 0, st, e.base(s), H, U.dw_w.p, U.dw_b.p, m.t2.p);
-        hipLaunchKernelGGL(k_layernorm_rows, dim3(T), dim3(256), 0, st, m.t2.p, H, U.ln_w.p, U.ln_b.p, H, 1e-6f, m.t2.p, H);
-        float* m1 = m.t1.p; // [T][4H]
-        m.run_conv(st, U.pw1, m.t2.p, H, T, m1, 4 * H, EPI_GELU);
+        hipLaunchKernelGGL(k_dwconv7, dim3((H + 255) / 256, T), dim3(256), 0, st, e.base(s), H, U.dw_w.p, U.dw_b.p, m.S->t2.p);
+        hipLaunchKernelGGL(k_layernorm_rows, dim3(T), dim3(256), 0, st, m.S->t2.p, H, U.ln_w.p, U.ln_b.p, H, 1e-6f, m.S->t2.p, H);
+        float* m1 = m.S->t1.p; // [T][4H]
+        m.run_conv(st, U.pw1, m.S->t2.p, H, T, m1, 4 * H, EPI_GELU);
         // y_new = y + gamma * (pw2(m1) + b): write into t2 (y lives in the ext buffer)
-        m.run_conv(st, U.pw2, m1, 4 * H, T, m.t2.p, H, EPI_RES_SCALE, e.cur(s), H, U.gamma.p);
+        m.run_conv(st, U.pw2, m1, 4 * H, T, m.S->t2.p, H, EPI_RES_SCALE, e.cur(s), H, U.gamma.p);
         m.shift(st, e, s, T);
         // next stage input must not alias its own output buffers: move to t1
-        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, m.t2.p, m.t1.p, (size_t)T * H);
-        x = m.t1.p;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, m.S->t2.p, m.S->t1.p, (size_t)T * H);
+        x = m.S->t1.p;
     }
     // 6. conv_in
     hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, x, m.convin_ext.cur(s), (size_t)T * H);
-    m.run_conv(st, m.conv_in, m.convin_ext.base(s), H, T, m.t1.p, m.dec_dim);
+    m.run_conv(st, m.conv_in, m.convin_ext.base(s), H, T, m.S->t1.p, m.dec_dim);
     m.shift(st, m.convin_ext, s, T);
-    float* d = m.t1.p; // [T][ch]
+    float* d = m.S->t1.p; // [T][ch]
     // 7. decoder blocks
     for (int b = 0; b < m.n_dec; b++) {
         auto& B = m.blk[b];
         Ext& ce = m.ct_ext[b];
         m.snake(st, B.snake, d, ce.cur(s), T);
-        float* y = (d == m.t1.p) ? m.t2.p : m.t1.p; // [T*r][co]
+        float* y = (d == m.S->t1.p) ? m.S->t2.p : m.S->t1.p; // [T*r][co]
         m.run_conv(st, B.ct, ce.base(s), B.cin, T, y, B.rate * B.cout);
         m.shift(st, ce, s, T);
         T *= B.rate;
@@ -692,9 +704,9 @@ int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int 
     }
     // 8. output conv
     m.snake(st, m.snake_out, d, m.out_ext.cur(s), T);
-    hipLaunchKernelGGL(k_conv_out, dim3((T + 255) / 256), dim3(256), 0, st, m.out_ext.base(s), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.pcm.p, T);
+    hipLaunchKernelGGL(k_conv_out, dim3((T + 255) / 256), dim3(256), 0, st, m.out_ext.base(s), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, T);
     m.shift(st, m.out_ext, s, T);
-    Q3_HIP(hipMemcpyAsync(pcm, m.pcm.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
+    Q3_HIP(hipMemcpyAsync(pcm, m.S->pcm.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
     return T;
 }
 

@@ -2,6 +2,10 @@
 #include "engine.h"
 #include <algorithm>
 #include <chrono>
+#include <condition_variable>
+#include <deque>
+#include <mutex>
+#include <thread>
 #include "kdev.h"
 
 namespace q3 {
@@ -19,8 +23,8 @@ static double now_ms() {
 
 Engine::Engine(const EngineParams& p) : p_(p) {
     Q3_CHECK(p.max_batch >= 1 && p.max_batch <= 512, "max_batch out of range");
+    Q3_HIP(hipGetDevice(&dev_));
     Q3_HIP(hipStreamCreate(&st_));
-    Q3_HIP(hipStreamCreate(&st2_));
     const std::string dir = p.model_dir + "/" + quant_dir(p.quant);
     assets_.reset(new HostAssets(dir + "/qwen3_assets.gguf"));
     const int B = p.max_batch;
@@ -89,7 +93,10 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     d_pposA_.alloc(posA.size()); d_pposA_.upload(posA.data(), posA.size());
     d_tseq_.upload(seq.data(), B);
     if (p.load_codec) {
-        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", B, 4));
+        const int n_lanes = std::min(B, 8);
+        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", B, 4, n_lanes));
+        st2_.resize(n_lanes);
+        for (auto& s2 : st2_) Q3_HIP(hipStreamCreate(&s2));
         pcm_pinned_cap_ = (size_t)B * p.max_steps * codec_->samples_per_frame();
         Q3_HIP(hipHostMalloc((void**)&pcm_pinned_, pcm_pinned_cap_ * sizeof(float)));
     }
@@ -101,7 +108,7 @@ Engine::~Engine() {
     if (graph_) (void)hipGraphDestroy(graph_);
     for (auto e : ev_pool_) (void)hipEventDestroy(e);
     if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
-    if (st2_) (void)hipStreamDestroy(st2_);
+    for (auto s2 : st2_) (void)hipStreamDestroy(s2);
     if (st_) (void)hipStreamDestroy(st_);
 }
 
@@ -243,22 +250,52 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
     std::vector<size_t> pcm_len(B, 0);        // samples enqueued so far per sequence (pinned staging area, slot b)
     std::vector<hipEvent_t> ev_first(B, nullptr);
     const size_t slot_cap = codec_ ? (size_t)p_.max_steps * spf : 0;
+    // decoder thread (the reference decodes on a second thread too, engine.rs:495-543): it owns every codec launch, so
+    // the ~200 kernel launches of a chunk never delay the AR stream's launches on this thread
+    struct DecTask { int b; std::vector<int64_t> codes; bool is_final; };
+    std::deque<DecTask> dq;
+    std::mutex dmu;
+    std::condition_variable dcv;
+    bool ddone = false;
+    std::string derr;
+    std::thread dec_thread;
+    const bool use_codec = codec_ && want_pcm;
+    if (use_codec) {
+        for (int b = 0; b < B; b++) codec_->reset(b);
+        dec_thread = std::thread([&]() {
+            try {
+                Q3_HIP(hipSetDevice(dev_)); // HIP's current device is per thread
+                for (;;) {
+                    DecTask t;
+                    {
+                        std::unique_lock<std::mutex> lk(dmu);
+                        dcv.wait(lk, [&] { return ddone || !dq.empty(); });
+                        if (dq.empty()) return;
+                        t = std::move(dq.front());
+                        dq.pop_front();
+                    }
+                    const int b = t.b, nf = (int)t.codes.size() / 16;
+                    Q3_CHECK(pcm_len[b] + (size_t)nf * spf <= slot_cap, "pcm staging overflow");
+                    const int lane = b % (int)st2_.size();
+                    // engine.rs:520: decode the chunk -- enqueued on a codec stream, overlapping the next AR frames
+                    const int got = codec_->decode_async(st2_[lane], b, t.codes.data(), nf, t.is_final, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b], lane);
+                    pcm_len[b] += (size_t)std::max(got, 0);
+                    stats.codec_calls++;
+                    if (!ev_first[b]) { Q3_HIP(hipEventCreate(&ev_first[b])); Q3_HIP(hipEventRecord(ev_first[b], st2_[lane])); } // first stream_tx.send, :522-523
+                }
+            } catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(dmu); derr = ex.what(); }
+        });
+    }
     for (int b = 0; b < B; b++) {
-        if (codec_ && want_pcm) codec_->reset(b);
-        chunkers.emplace_back(new Chunker([this, b, spf, want_pcm, &pcm_len, &ev_first, slot_cap](const int64_t* codes, int n_codes, bool is_final) {
-            if (!codec_ || !want_pcm) return;
-            const int nf = n_codes / 16;
-            Q3_CHECK(pcm_len[b] + (size_t)nf * spf <= slot_cap, "pcm staging overflow");
-            // engine.rs:520: decode the chunk -- enqueued on the codec stream, overlapping the next AR frames
-            const int got = codec_->decode_async(st2_, b, codes, nf, is_final, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b]);
-            pcm_len[b] += (size_t)std::max(got, 0);
-            stats.codec_calls++;
-            if (!ev_first[b]) { Q3_HIP(hipEventCreate(&ev_first[b])); Q3_HIP(hipEventRecord(ev_first[b], st2_)); } // first stream_tx.send, :522-523
+        chunkers.emplace_back(new Chunker([&, b](const int64_t* codes, int n_codes, bool is_final) {
+            if (!use_codec) return;
+            { std::lock_guard<std::mutex> lk(dmu); dq.push_back(DecTask{b, std::vector<int64_t>(codes, codes + n_codes), is_final}); }
+            dcv.notify_one();
         }));
     }
     hipEvent_t ev_t0;
     Q3_HIP(hipEventCreate(&ev_t0));
-    Q3_HIP(hipEventRecord(ev_t0, st2_)); // st2_ is idle here: marks "prefill done" on the codec stream's clock
+    Q3_HIP(hipEventRecord(ev_t0, st_)); // the AR stream is idle here (prefill was synchronised): marks "prefill done"
 
     // ---------------- frame loop ----------------
     code0_given_ = any_sampled;
@@ -315,7 +352,13 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
     for (int b = 0; b < B; b++) chunkers[b]->push(nullptr, 0, true); // :644
     {
         const double c0 = now_ms();
-        Q3_HIP(hipStreamSynchronize(st2_));  // join the decoder (engine.rs:647-649)
+        if (use_codec) {
+            { std::lock_guard<std::mutex> lk(dmu); ddone = true; }
+            dcv.notify_one();
+            dec_thread.join();                                   // engine.rs:647-649
+            if (!derr.empty()) throw Error("decoder thread: " + derr);
+        }
+        for (auto s2 : st2_) Q3_HIP(hipStreamSynchronize(s2));
         stats.codec_ms += now_ms() - c0;     // only the part of the codec work the AR loop did not hide
     }
     for (int b = 0; b < B; b++) {

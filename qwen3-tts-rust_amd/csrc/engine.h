@@ -61,7 +61,8 @@ private:
     void record_frame(int B);           // enqueue one frame step for B sequences on st_
     void build_graph(int B);
     EngineParams p_;
-    hipStream_t st_ = nullptr, st2_ = nullptr; // st2_: codec decoder, overlapped with the next AR frames
+    hipStream_t st_ = nullptr; int dev_ = 0;
+    std::vector<hipStream_t> st2_; // codec decoder lanes: overlapped with the next AR frames and with each other
     float* pcm_pinned_ = nullptr; size_t pcm_pinned_cap_ = 0;
     std::unique_ptr<HostAssets> assets_;
     std::unique_ptr<Transformer> talker_, predictor_;

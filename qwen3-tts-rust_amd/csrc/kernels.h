@@ -113,6 +113,7 @@ struct ArgmaxEpi {
 };
 void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride,
                          int ntok, const ArgmaxEpi* am);
+void launch_rmsnorm_quant_wg(hipStream_t st, const NormPro& a, int d, int8_t* xq, uint16_t* xd, int ntok);
 void launch_gateup_swiglu(hipStream_t st, const Q8Mat& wgu, int ff, const NormPro& a, int8_t* aq, uint16_t* ad, int ntok);
 void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,

@@ -127,6 +127,24 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
     if ((lane & 7) == 0) xd_dst[8 * c + (lane >> 3)] = f2h(dd);
 }
 
+// standalone workgroup-per-token norm + quant (batched-step path): same arithmetic as k_rmsnorm_quant, one global
+// round trip instead of a serial chain in a single wave
+__global__ void __launch_bounds__(512) k_rmsnorm_quant_wg(NormPro a, int d, int8_t* __restrict__ xq, uint16_t* __restrict__ xd) {
+    __shared__ __attribute__((aligned(16))) int8_t xq_s[2048];
+    __shared__ __attribute__((aligned(16))) uint16_t xd_s[64];
+    __shared__ __attribute__((aligned(16))) float vbuf_s[2048];
+    __shared__ float scal_s[1];
+    const int tok = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    norm_quant_wg(a, d, tok, true, lane, wave, xq_s, xd_s, vbuf_s, scal_s, true);
+    __syncthreads();
+    for (int i = threadIdx.x; i < d / 16; i += blockDim.x)
+        *reinterpret_cast<uint4*>(xq + (size_t)tok * d + 16 * i) = *reinterpret_cast<const uint4*>(xq_s + 16 * i);
+    for (int i = threadIdx.x; i < d / 32; i += blockDim.x) xd[(size_t)tok * (d / 32) + i] = xd_s[i];
+}
+void launch_rmsnorm_quant_wg(hipStream_t st, const NormPro& a, int d, int8_t* xq, uint16_t* xd, int ntok) {
+    hipLaunchKernelGGL(k_rmsnorm_quant_wg, dim3(ntok), dim3(64 * (d / 256)), 0, st, a, d, xq, xd);
+}
+
 // ===================================================================================================
 // A: norm prologue + GEMV (K = d <= 2048, one super-segment).  EPI 0: store f32; EPI 1: atomic argmax.
 // ===================================================================================================

@@ -184,13 +184,23 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         if (hidden_out) head(st, 0, ntok, 0, 0, nullptr, 0, nullptr, -1, hidden_out);
         return;
     }
+    const bool wgnorm = ntok > 8; // batched steps: workgroup-per-token norm kernel (same arithmetic, one global round trip)
+    auto norm = [&](const NormArgs& a) {
+        if (!wgnorm) { launch_rmsnorm_quant(st, a, ntok); return; }
+        NormPro p{};
+        p.h_in = a.h_in; p.h_stride = a.h_stride; p.idx_keys = a.idx_keys; p.idx_stride = a.idx_stride; p.parts = a.parts; p.nparts = a.nparts;
+        p.parts_stride = a.parts_stride; p.parts_slab = (size_t)ntok * a.parts_stride; p.h_out = a.h_out; p.g = a.g; p.eps = a.eps; p.xn_out = a.xn_out;
+        Q3_CHECK(a.idx == nullptr, "int32 row indices are not supported on the batched path");
+        launch_rmsnorm_quant_wg(st, p, a.d, a.xq, a.xd, ntok);
+    };
+    // NB the wg kernel forbids h_out aliasing h_in only across workgroups; here each token is one workgroup, so in-place is safe
     for (int l = 0; l < hp_.n_layer; l++) {
         const Layer& L = layers_[l];
         NormArgs a{};
         if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx = in.idx; a.idx_keys = in.idx_keys; a.idx_stride = in.idx_stride; a.nparts = 0; }
         else { a.h_in = h_.p; a.h_stride = d; a.parts = parts_d_.p; a.nparts = nparts_d_; a.parts_stride = d; }
         a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p;
-        launch_rmsnorm_quant(st, a, ntok);
+        norm(a);
         gemv(st, L.wqkv, 0, dq + 2 * dkv, xq_.p, xd_.p, qkv_.p, dq + 2 * dkv, ntok);
         launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                               rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
@@ -199,7 +209,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         NormArgs b{};
         b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.h_out = h_.p;
         b.g = L.ffn_norm; b.eps = hp_.eps; b.d = d; b.xq = xq_.p; b.xd = xd_.p;
-        launch_rmsnorm_quant(st, b, ntok);
+        norm(b);
         gemv(st, L.wgu, 0, 2 * ff, xq_.p, xd_.p, gu_.p, 2 * ff, ntok);
         launch_swiglu_quant(st, gu_.p, ff, fq_.p, fd_.p, ntok);
         gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
@@ -207,7 +217,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     NormArgs f{};
     f.h_in = h_.p; f.h_stride = d; f.parts = parts_d_.p; f.nparts = nparts_d_; f.parts_stride = d; f.h_out = nullptr;
     f.g = output_norm_; f.eps = hp_.eps; f.d = d; f.xq = xq_.p; f.xd = xd_.p; f.xn_out = hidden_out ? hidden_out : hid_.p;
-    launch_rmsnorm_quant(st, f, ntok);
+    norm(f);
 }
 
 void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
