@@ -15,6 +15,10 @@ struct Q8Mat {
     int N = 0;      // logical rows
     int Npad = 0;   // rows padded to 32
     int K = 0;
+    // K-quant support (Q5_K / Q6_K rows expanded to int8 planes at load, exact): per-row-group ggml type and a 16-B metadata
+    // vector per (row, segment): Q5_K = {sc[8], m[8]} u8 with d,dmin in sc[0..1]; Q6_K = 16 i8 sub-block scales with d in sc[0].
+    const uint8_t* rg_type = nullptr;   // [Npad/32], null => all Q8_0
+    const uint8_t* meta = nullptr;      // [N/32][K/256][32 rows][16 B]
     size_t bytes() const { return (size_t)Npad * K + (size_t)Npad * (K / 32) * 2; }
 };
 

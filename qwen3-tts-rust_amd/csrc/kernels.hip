@@ -84,6 +84,113 @@ __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __rest
 __global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok);
 
+// =====================================================================================================
+// Mixed-type form (Q5_K_M files: Q5_K + Q6_K + Q8_0 rows in one fused matrix).  Same wave mapping and the same
+// int8 tile layout as k_gemv_q8; the per-block arithmetic follows the weight type of the row group (spec S3):
+//   Q8_0: acc = fma(f(isum), dw*dx, acc)
+//   Q5_K: acc = fma(d*f(sc*isum1) - dmin*f(m*isum2), dx, acc)      isum2 = sum of the activation block
+//   Q6_K: acc = fma(d*f(sc0*isum_lo + sc1*isum_hi), dx, acc)        (the two 16-element halves are the sub-blocks)
+// =====================================================================================================
+template <int LPR, int MT>
+__global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
+                                                 const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride, int ntok) {
+    constexpr int R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    __shared__ float red[8][R * MT];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    const int tok0 = blockIdx.z * MT;
+    const bool active = seg < nseg;
+    float acc[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) acc[m] = 0.0f;
+    if (active) {
+        int row = row0 + blockIdx.x * R + r;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const int wt = w.rg_type ? w.rg_type[rg] : Q3_T_Q8_0;
+        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+        uint4 wv[NLD];
+#pragma unroll
+        for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
+        const size_t vidx = ((size_t)rg * nseg + seg) * 32 + r32;
+        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + vidx * 8);
+        uint4 mv = make_uint4(0, 0, 0, 0);
+        if (wt != Q3_T_Q8_0) mv = *reinterpret_cast<const uint4*>(w.meta + vidx * 16);
+        const float d0 = h2f(half_of(dwv, 0)), d1 = h2f(half_of(dwv, 1)); // K-quants: d, dmin
+        auto mbyte = [&](int k) -> int { const uint32_t ww = k < 4 ? mv.x : k < 8 ? mv.y : k < 12 ? mv.z : mv.w; return (int)((ww >> (8 * (k & 3))) & 0xFFu); };
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            int tok = tok0 + m;
+            if (tok > ntok - 1) tok = ntok - 1;
+            const int8_t* xp = xq + (size_t)tok * w.K + seg * 256;
+            const uint4 dxv = *reinterpret_cast<const uint4*>(xd + (size_t)tok * nb + seg * 8);
+#pragma unroll
+            for (int i = 0; i < NLD; i++) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(xp + (i * BPL + bil) * 32 + half * 16);
+                int isum = dot16(wv[i], xv);
+                int xsum = 0;
+                if (wt == Q3_T_Q5_K) {
+                    const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
+                    xsum = dot16(ones, xv);
+                    xsum += __shfl_xor(xsum, R);
+                } else if (wt == Q3_T_Q6_K) {
+                    const int bsel = i * BPL + bil; // block index inside the segment of THIS lane's data
+                    isum *= (int)(int8_t)mbyte(2 * bsel + half);
+                }
+                isum += __shfl_xor(isum, R);
+#pragma unroll
+                for (int j = 0; j < BPL; j++) {
+                    const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
+                    const int xsj = (BPL == 1) ? xsum : __shfl(xsum, r + 2 * j * R);
+                    const int b = i * BPL + j;
+                    const float dxf = h2f(half_of(dxv, b));
+                    if (wt == Q3_T_Q8_0) {
+                        const float sc = h2f(half_of(dwv, b)) * dxf;
+                        acc[m] = q3_fmaf((float)isj, sc, acc[m]);
+                    } else if (wt == Q3_T_Q5_K) {
+                        const int i1 = mbyte(b) * isj, i2 = mbyte(8 + b) * xsj;
+                        const float a = d0 * (float)i1;
+                        const float a2 = d1 * (float)i2;
+                        const float diff = a - a2;
+                        acc[m] = q3_fmaf(diff, dxf, acc[m]);
+                    } else {
+                        const float a = d0 * (float)isj;
+                        acc[m] = q3_fmaf(a, dxf, acc[m]);
+                    }
+                }
+            }
+        }
+        if (q == 0) {
+#pragma unroll
+            for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
+        }
+    }
+    __syncthreads();
+    for (int t = threadIdx.x; t < R * MT; t += blockDim.x) {
+        const int m = t / R, rr = t % R;
+        int nsg = nseg - sseg * 8;
+        if (nsg > 8) nsg = 8;
+        float S = red[0][t];
+        for (int s = 1; s < nsg; s++) S = S + red[s][t];
+        const int orow = blockIdx.x * R + rr, tok = tok0 + m;
+        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+    }
+}
+template <int LPR>
+static void gemv_kq_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
+                       int out_stride, int ntok) {
+    constexpr int R = 64 / LPR;
+    const int nseg = w.K >> 8, nsseg = (nseg + 7) / 8, nw = nseg < 8 ? nseg : 8;
+    const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : ntok <= 4 ? 4 : 8;
+    dim3 grid((nrows + R - 1) / R, nsseg, (ntok + mt - 1) / mt);
+    if (mt == 1) hipLaunchKernelGGL((k_gemv_kq<LPR, 1>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemv_kq<LPR, 2>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else if (mt == 4) hipLaunchKernelGGL((k_gemv_kq<LPR, 4>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    else hipLaunchKernelGGL((k_gemv_kq<LPR, 8>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+}
+
 template <int LPR, int MT>
 static void gemv_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
                         float* out, int out_stride, int ntok) {
@@ -104,6 +211,14 @@ static void gemv_launch_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, 
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
                     float* out, int out_stride, int ntok, int lpr_hint) {
     const int nsseg = ((w.K >> 8) + 7) / 8;
+    if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
+        int lpr = lpr_hint;
+        if (!lpr) lpr = ((long)(nrows / 32) * nsseg >= 512) ? 2 : ((long)(nrows / 16) * nsseg >= 256) ? 4 : 8;
+        if (lpr == 2) gemv_kq_mt<2>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+        else if (lpr == 4) gemv_kq_mt<4>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+        else gemv_kq_mt<8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+        return;
+    }
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         hipLaunchKernelGGL(k_gemm_q8_mfma, dim3((nrows + 31) / 32, nsseg, (ntok + 31) / 32), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,

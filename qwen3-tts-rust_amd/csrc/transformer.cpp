@@ -20,6 +20,66 @@ __global__ void k_repack_q8(const uint8_t* __restrict__ raw, int n, int K, int r
     for (int i = 0; i < 16; i++) { dst[i] = src[2 + i]; dst[512 + i] = src[18 + i]; }
 }
 
+// Q5_K super-block {f16 d, dmin; u8 scales[12]; u8 qh[32]; u8 qs[128]} -> int8 plane (q in 0..31) + {d,dmin} + {sc[8], m[8]}
+__global__ void k_repack_q5k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, uint16_t* __restrict__ sc,
+                             uint8_t* __restrict__ meta) {
+    const int nb = K >> 5, nseg = K >> 8;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * nseg) return;
+    const int r = (int)(id / nseg), s = (int)(id % nseg);
+    const uint8_t* blk = raw + id * 176;
+    const int row = row_off + r, rg = row >> 5, r32 = row & 31;
+    const size_t vidx = ((size_t)rg * nseg + s) * 32 + r32;
+    uint16_t d, dm;
+    memcpy(&d, blk, 2); memcpy(&dm, blk + 2, 2);
+    for (int i = 0; i < 8; i++) sc[vidx * 8 + i] = i == 0 ? d : i == 1 ? dm : 0;
+    const uint8_t *scales = blk + 4, *qh = blk + 16, *ql = blk + 48;
+    for (int j = 0; j < 8; j++) {
+        int scv, mv;
+        if (j < 4) { scv = scales[j] & 63; mv = scales[j + 4] & 63; }
+        else { scv = (scales[j + 4] & 0xF) | ((scales[j - 4] >> 6) << 4); mv = (scales[j + 4] >> 4) | ((scales[j] >> 6) << 4); }
+        meta[vidx * 16 + j] = (uint8_t)scv; meta[vidx * 16 + 8 + j] = (uint8_t)mv;
+        const int jj = j >> 1, hi = j & 1;
+        uint8_t* dst = qs + ((size_t)rg * nb + (size_t)s * 8 + j) * 1024 + r32 * 16;
+        for (int l = 0; l < 32; l++) {
+            const int nib = hi ? (ql[32 * jj + l] >> 4) : (ql[32 * jj + l] & 0xF);
+            const int hb = (qh[l] >> (2 * jj + hi)) & 1;
+            dst[(l >> 4) * 512 + (l & 15)] = (uint8_t)(nib + 16 * hb);
+        }
+    }
+}
+// Q6_K super-block {u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d} -> int8 plane (q-32) + d + 16 sub-block scales
+__global__ void k_repack_q6k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, uint16_t* __restrict__ sc,
+                             uint8_t* __restrict__ meta) {
+    const int nb = K >> 5, nseg = K >> 8;
+    const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (id >= (size_t)n * nseg) return;
+    const int r = (int)(id / nseg), s = (int)(id % nseg);
+    const uint8_t* blk = raw + id * 210;
+    const int row = row_off + r, rg = row >> 5, r32 = row & 31;
+    const size_t vidx = ((size_t)rg * nseg + s) * 32 + r32;
+    uint16_t d;
+    memcpy(&d, blk + 208, 2);
+    for (int i = 0; i < 8; i++) sc[vidx * 8 + i] = i == 0 ? d : 0;
+    for (int i = 0; i < 16; i++) meta[vidx * 16 + i] = blk[192 + i];
+    for (int j = 0; j < 8; j++) {
+        const int half = j >> 2, grp = j & 3;
+        const uint8_t* L = blk + 64 * half;
+        const uint8_t* H = blk + 128 + 32 * half;
+        uint8_t* dst = qs + ((size_t)rg * nb + (size_t)s * 8 + j) * 1024 + r32 * 16;
+        for (int l = 0; l < 32; l++) {
+            int q;
+            switch (grp) {
+                case 0: q = (L[l] & 0xF) | (((H[l] >> 0) & 3) << 4); break;
+                case 1: q = (L[l + 32] & 0xF) | (((H[l] >> 2) & 3) << 4); break;
+                case 2: q = (L[l] >> 4) | (((H[l] >> 4) & 3) << 4); break;
+                default: q = (L[l + 32] >> 4) | (((H[l] >> 6) & 3) << 4); break;
+            }
+            dst[(l >> 4) * 512 + (l & 15)] = (uint8_t)(int8_t)(q - 32);
+        }
+    }
+}
+
 Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& storage) {
     Q3_CHECK(k % 256 == 0 && n > 0, "bad Q8_0 matrix shape");
     Q8Mat m;
@@ -44,24 +104,39 @@ Q8Mat Transformer::make_mat(int N, int K) {
     Q8Mat m;
     m.N = N; m.Npad = (N + 31) & ~31; m.K = K;
     const size_t qs_bytes = (size_t)m.Npad * K, sc_bytes = (size_t)m.Npad * (K / 32) * 2;
-    blobs_.emplace_back(qs_bytes + sc_bytes);
+    const size_t meta_bytes = (size_t)m.Npad * (K / 256) * 16, ty_bytes = (size_t)((m.Npad / 32 + 15) & ~15);
+    blobs_.emplace_back(qs_bytes + sc_bytes + meta_bytes + ty_bytes);
     blobs_.back().zero();
     m.qs = blobs_.back().p;
     m.sc = reinterpret_cast<const uint16_t*>(blobs_.back().p + qs_bytes);
+    mat_meta_[m.qs] = blobs_.back().p + qs_bytes + sc_bytes;            // attached to the Q8Mat only if a K-quant row group shows up
+    mat_types_[m.qs] = blobs_.back().p + qs_bytes + sc_bytes + meta_bytes;
     return m;
 }
 
 void Transformer::load_into(const Gguf& g, const std::string& name, Q8Mat& dst, int row_off, int K_expect) {
     const GgufTensor& t = g.need(name);
-    if (t.type != Q3_T_Q8_0)
-        throw Error("tensor " + name + ": type " + std::to_string(t.type) + " not supported by the HIP path yet (Q8_0 only)");
+    if (t.type != Q3_T_Q8_0 && t.type != Q3_T_Q5_K && t.type != Q3_T_Q6_K)
+        throw Error("tensor " + name + ": ggml type " + std::to_string(t.type) + " is not supported by the HIP path (Q8_0, Q5_K, Q6_K)");
     Q3_CHECK(t.ne[0] == K_expect, "unexpected K for " + name);
-    Q3_CHECK(row_off % 32 == 0 && row_off + t.ne[1] <= dst.Npad, "bad row offset for " + name);
+    Q3_CHECK(row_off % 32 == 0 && row_off + t.ne[1] <= dst.Npad && t.ne[1] % 32 == 0, "bad row range for " + name);
     DevBuf<uint8_t> raw(t.nbytes);
     raw.upload(t.data, t.nbytes);
-    const size_t nblk = (size_t)t.ne[1] * (t.ne[0] / 32);
-    hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0],
-                       row_off, const_cast<uint8_t*>(dst.qs), const_cast<uint16_t*>(dst.sc));
+    uint8_t* qs = const_cast<uint8_t*>(dst.qs);
+    uint16_t* sc = const_cast<uint16_t*>(dst.sc);
+    uint8_t* meta = mat_meta_.at(dst.qs);
+    uint8_t* types = mat_types_.at(dst.qs);
+    if (t.type == Q3_T_Q8_0) {
+        const size_t nblk = (size_t)t.ne[1] * (t.ne[0] / 32);
+        hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc);
+    } else {
+        const size_t nsb = (size_t)t.ne[1] * (t.ne[0] / 256);
+        if (t.type == Q3_T_Q5_K) hipLaunchKernelGGL(k_repack_q5k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc, meta);
+        else hipLaunchKernelGGL(k_repack_q6k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc, meta);
+        dst.meta = meta; dst.rg_type = types; all_q8_ = false;
+    }
+    std::vector<uint8_t> ty((size_t)t.ne[1] / 32, (uint8_t)t.type);
+    Q3_HIP(hipMemcpy(types + row_off / 32, ty.data(), ty.size(), hipMemcpyHostToDevice));
     Q3_HIP(hipDeviceSynchronize());
 }
 
@@ -119,6 +194,7 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     hp_.n_vocab = (int)ot.ne[1];
     output_ = make_mat(hp_.n_vocab, d);
     load_into(g, "output.weight", output_, 0, d);
+    if (!all_q8_) fused = false; // the fused decode kernels are Q8_0-only; K-quant files run the 9-launch sequence (same arithmetic)
     // RoPE tables: same double-precision expressions as the oracle (spec S5)
     std::vector<float> c((size_t)n_ctx * 64), s((size_t)n_ctx * 64);
     for (int p = 0; p < n_ctx; p++)

@@ -4,6 +4,7 @@
 #include "q3_common.h"
 #include "gguf.h"
 #include "kernels.h"
+#include <map>
 #include <memory>
 
 namespace q3 {
@@ -66,7 +67,8 @@ private:
     DevBuf<int32_t> d_mrope_;
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
-    bool same_seq_ = false; bool last_fused_ = false; int last_ntok_ = 0;
+    bool same_seq_ = false; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
+    std::map<const uint8_t*, uint8_t*> mat_meta_, mat_types_;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
     int nparts_d_ = 1;

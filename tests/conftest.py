@@ -42,6 +42,10 @@ def tiny_model(synth_tool):
         _run([synth_tool, "--out", out, "--preset", "tiny", "--quant", "q5_k_m", "--what", "3"])
         _run([synth_tool, "--out", out, "--preset", "tiny", "--quant", "bf16", "--what", "3"])
         open(os.path.join(out, ".complete3"), "w").write("ok")
+    for sub in ("gguf_q5_k_m", "gguf_bf16"):   # the assets file is F32 in every quantisation directory (assets_manager.rs:163-167)
+        dst = os.path.join(out, sub, "qwen3_assets.gguf")
+        if not os.path.exists(dst):
+            os.symlink(os.path.join(out, "gguf_q8_0", "qwen3_assets.gguf"), dst)
     return out
 
 

@@ -192,6 +192,22 @@ def test_engine_batch_equals_singles(tiny_engines, vivian):
     assert all(np.array_equal(a["codes"], b["codes"]) for a, b in zip(two, batch))
 
 
+def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
+    """BASELINE.json configs[0] quantisation (Q5_K_M = Q5_K + Q6_K rows) on the GPU: K-quant rows are expanded to int8 planes at
+    load (exact) and run through the mixed-type GEMV; tokens must equal the oracle's Q5_K/Q6_K block arithmetic bit for bit."""
+    qdir = os.path.join(tiny_model, "gguf_q5_k_m")
+    for name, d, npre in (("qwen3_tts_talker.gguf", 2048, 21), ("qwen3_tts_predictor.gguf", 256, 2)):
+        _tf_parity(gpu, oracle, os.path.join(qdir, name), d, npre, 4, 2048)
+    ge = gpu.Engine(tiny_model, "q5_k_m", max_batch=2, max_steps=32, load_codec=False)
+    oe = oracle.Engine(qdir, None, 4)
+    prompts = [ge.assets.build_core(np.arange(100, 100 + n, dtype=np.int32), lang_id=2055, spk_emb=vivian) for n in (8, 15)]
+    res = ge.generate_batch(prompts, max_steps=8, mask_eos=True)
+    for p, r in zip(prompts, res):
+        oc, _ = oe.generate(p, max_steps=8, mask_eos=True)
+        assert np.array_equal(oc, r["codes"])
+    ge.close(); oe.close()
+
+
 def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
     path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
     rng = np.random.default_rng(8)
