@@ -92,7 +92,6 @@ int q3tts_op_project(const float* x, const float* w, const float* b, int32_t n_i
     Q3_API_END(Q3TTS_ERR)
 }
 
-int q3tts_mel(const float*, int32_t, float*) { set_last_error("mel kernel not built yet"); return Q3TTS_ERR; }
 int q3tts_mel_frames(int32_t n) { const int plen = n + 768; return (plen > 1024 ? plen - 1024 : 0) / 256 + 1; }
 
 } // extern "C"

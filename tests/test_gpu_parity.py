@@ -224,6 +224,17 @@ def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
     gd.close()
 
 
+def test_mel_kernel_vs_oracle(gpu, oracle):
+    """row a16: log-mel front end (onnx.rs:167-320) on the device vs the oracle; float tolerance (f32 DFT vs double FFT)."""
+    rng = np.random.default_rng(12)
+    t = np.arange(24000 * 3) / 24000.0
+    chirp = (0.4 * np.sin(2 * np.pi * (200 + 3000 * t) * t) + 0.05 * rng.standard_normal(t.size)).astype(np.float32)
+    for audio in (chirp, chirp[:5000], chirp[:300], np.zeros(1500, np.float32)):
+        ref = oracle.mel(audio)
+        got = gpu.mel(audio)
+        assert got.shape == ref.shape and np.abs(got - ref).max() < 2e-3
+
+
 def test_llama_abi_replay_matches_oracle(gpu, oracle, tiny_model, vivian, tmp_path):
     """Boundary A: the reference's loop, replayed call-for-call through runtime/libllama.so (dlopen'd from cwd/runtime)."""
     pkg = os.path.join(ROOT, "qwen3-tts-rust_amd")
