@@ -174,7 +174,9 @@ def main():
         si = eng.stats()
         mean_ctx = prompt.shape[0] + n_frames / 2.0
         step_bytes = eng.bytes_per_step(args.batch, mean_ctx)
-        gemv_gbs = si["gemv_bytes"] / (si["gemv_ms"] * 1e-3) / 1e9 if si["gemv_ms"] > 0 else 0.0
+        fam_bytes, fam_ms, fam_n = si["gemv_bytes"] + si["gu_bytes"], si["gemv_ms"] + si["gu_ms"], si["gemv_launches"] + si["gu_launches"]
+        gemv_gbs = fam_bytes / (fam_ms * 1e-3) / 1e9 if fam_ms > 0 else 0.0
+        gu_gbs = si["gu_bytes"] / (si["gu_ms"] * 1e-3) / 1e9 if si["gu_ms"] > 0 else 0.0
         frame_ms = st["frame_loop_ms"] / max(st["frames"] / args.batch, 1)   # one batched step advances every sequence by a frame
         out = {
             "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
@@ -190,10 +192,15 @@ def main():
             "prefill_ms": st["prefill_ms"],
             "codec_ms_per_chunk": (st["codec_ms"] / st["codec_calls"]) if st["codec_calls"] else None,
             "frame_hbm_frac": (step_bytes / (frame_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if frame_ms > 0 else None,
-            "roofline": {"bound": "hbm", "kernel": "k_gemv_q8 (all instantiations; %d launches)" % si["gemv_launches"],
-                         "achieved": gemv_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gemv_gbs / HBM_PEAK_GBS,
-                         "avg_launch_us": 1e3 * si["gemv_ms"] / max(si["gemv_launches"], 1),
-                         "bytes_per_launch": si["gemv_bytes"] / max(si["gemv_launches"], 1), "traffic": None},
+            # dominant kernel by algorithmic bytes: the talker's fused gate/up kernel (26.7 MB of Q8_0 weights per launch, 28 per frame)
+            "roofline": {"bound": "hbm", "kernel": "q3::k_gateup_swiglu<1> (talker: norm + gate/up GEMV + SwiGLU + quant; %d launches)" % si["gu_launches"],
+                         "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
+                         "avg_launch_us": 1e3 * si["gu_ms"] / max(si["gu_launches"], 1),
+                         "bytes_per_launch": si["gu_bytes"] / max(si["gu_launches"], 1),
+                         "traffic": 27.09e6,  # profiles/r01_hbm_traffic_pmc.md: FETCH_SIZE 13230 KiB x 2 (gfx950 correction) per launch
+                         "method": "HIP-event pair around every launch in an eager replay of the same K steps (adds ~1-2 us over rocprof's kernel time)",
+                         "family_all_gemv": {"achieved": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS, "launches": fam_n,
+                                             "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1)}},
         }
         log("instrumented leg done")
         if world == 1 and not args.no_cpu_baseline:

@@ -79,6 +79,7 @@ typedef struct q3tts_stats {
     double gemv_ms; int64_t gemv_launches; double gemv_bytes; /* instrumented leg only */
     double codec_ms; int64_t codec_calls;
     double talker_weight_bytes, predictor_weight_bytes, kv_bytes_per_token;
+    double gu_ms; int64_t gu_launches; double gu_bytes;       /* talker gate/up kernel alone (instrumented leg) */
 } q3tts_stats;
 int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* out);
 void q3tts_engine_reset_stats(q3tts_engine* e);

@@ -31,6 +31,9 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     B_ = B;
     talker_.reset(new Transformer(dir + "/qwen3_tts_talker.gguf", Q3_TALKER_NCTX, std::max(256, B)));
     predictor_.reset(new Transformer(dir + "/qwen3_tts_predictor.gguf", Q3_PRED_NCTX, 2 * B));
+    // experiment switch: fold the predictor's attention into its o-proj launch (k_oproj_attn).  Measured on MI355X: 3.23 vs
+    // 3.07 ms/frame -- the single-wave attention chain costs more than the launch it removes, so it stays off by default.
+    if (const char* e = std::getenv("Q3_FOLD_ATTN")) predictor_->set_short_context(e[0] == '1');
     Q3_CHECK(talker_->hp().n_embd == Q3_EMBD, "talker n_embd must be 2048 (reference hard-codes 2048-wide rows)");
     dP_ = predictor_->hp().n_embd;
     Q3_CHECK(assets_->proj_out == dP_ && assets_->proj_in == Q3_EMBD, "proj shape does not match predictor n_embd");
@@ -299,9 +302,9 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
 
     // ---------------- frame loop ----------------
     code0_given_ = any_sampled;
-    LaunchTimer timer;
+    LaunchTimer timer, timer_gu;
     const bool eager = instrument_ || !p_.use_graph;
-    if (instrument_) { talker_->timer = &timer; predictor_->timer = &timer; }
+    if (instrument_) { talker_->timer = &timer; predictor_->timer = &timer; talker_->timer_gu = &timer_gu; }
     if (!eager) build_graph(W);
     std::vector<int32_t> fed(B, 0), hbuf;
     std::vector<float> hlogits;
@@ -327,7 +330,10 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
         Q3_HIP(hipEventRecord(ev1, st_));
         Q3_HIP(hipStreamSynchronize(st_));
         { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, ev0, ev1)); stats.frame_loop_ms += ms; }
-        if (instrument_) { stats.gemv_ms += timer.collect_ms(); stats.gemv_bytes += timer.bytes; stats.gemv_launches += timer.launches; timer.bytes = 0; timer.launches = 0; }
+        if (instrument_) {
+            stats.gemv_ms += timer.collect_ms(); stats.gemv_bytes += timer.bytes; stats.gemv_launches += timer.launches; timer.bytes = 0; timer.launches = 0;
+            stats.gu_ms += timer_gu.collect_ms(); stats.gu_bytes += timer_gu.bytes; stats.gu_launches += timer_gu.launches; timer_gu.bytes = 0; timer_gu.launches = 0;
+        }
         step += group;
         d_nframes_.download(nfr.data(), W); d_finished_.download(fin.data(), W);
         all_done = true;
@@ -348,7 +354,7 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
             if (!fin[b] && nfr[b] < reqs[b].max_steps) all_done = false;
         }
     }
-    talker_->timer = nullptr; predictor_->timer = nullptr;
+    talker_->timer = nullptr; predictor_->timer = nullptr; talker_->timer_gu = nullptr;
     for (int b = 0; b < B; b++) chunkers[b]->push(nullptr, 0, true); // :644
     {
         const double c0 = now_ms();

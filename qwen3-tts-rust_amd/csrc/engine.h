@@ -38,7 +38,8 @@ struct GenResult {
 
 struct EngineStats { // accumulated over generate_batch calls since reset
     double frame_loop_ms = 0; long frames = 0;   // device time of the AR frame loop (HIP events), all sequences
-    double gemv_ms = 0; long gemv_launches = 0; double gemv_bytes = 0; // instrumented (eager) leg only
+    double gemv_ms = 0; long gemv_launches = 0; double gemv_bytes = 0; // instrumented (eager) leg only: GEMV family except ...
+    double gu_ms = 0; long gu_launches = 0; double gu_bytes = 0;       // ... the talker's gate/up kernel, timed on its own
     double codec_ms = 0; long codec_calls = 0;
     double prefill_ms = 0;
 };

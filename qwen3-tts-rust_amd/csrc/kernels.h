@@ -123,6 +123,9 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                             const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad,
                             int ntok);
+void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
+                       const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
+                       const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok);
 void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
                          float* out, int out_stride, int ntok);
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk /*[n_out/16][n_in][16]*/, const float* b,

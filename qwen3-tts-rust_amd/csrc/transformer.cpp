@@ -243,17 +243,23 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
                 launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                                       rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
                 launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
+            } else if (short_ctx_ && dq == 2048 && hp_.n_head == 2 * hp_.n_kv) {
+                if (timer) timer->begin(st);
+                launch_oproj_attn(st, L.wo, d, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                                  n_ctx_, d_mrope_.p, tm, kv, l, parts_o_.p, d, ntok);
+                if (timer) timer->end(st, (double)L.wo.bytes());
             } else {
                 launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                                        rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
             }
-            gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
+            if (same_seq_ || !(short_ctx_ && dq == 2048 && hp_.n_head == 2 * hp_.n_kv)) gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
             NormPro b{};
             b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.parts_slab = (size_t)ntok * d; b.h_out = h2_.p;
             b.g = L.ffn_norm; b.eps = hp_.eps;
-            if (timer) timer->begin(st);
+            LaunchTimer* tg = timer_gu ? timer_gu : timer;
+            if (tg) tg->begin(st);
             launch_gateup_swiglu(st, L.wgu, ff, b, fq_.p, fd_.p, ntok);
-            if (timer) timer->end(st, (double)L.wgu.bytes());
+            if (tg) tg->end(st, (double)L.wgu.bytes());
             gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
         }
         // final norm is the prologue of head(); hidden_out is produced there too

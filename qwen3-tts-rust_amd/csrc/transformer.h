@@ -41,8 +41,11 @@ public:
     void head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
               const ArgmaxEpi* am = nullptr, int nrows_valid = -1, float* hidden_out = nullptr);
     void set_same_seq_tokens(bool v) { same_seq_ = v; }
+    // every cached context of this model stays <= 64 positions (the code predictor): fold attention into the o-proj launch
+    void set_short_context(bool v) { short_ctx_ = v; }
 
-    LaunchTimer* timer = nullptr; // optional per-GEMV-launch event timing (instrumented bench leg)
+    LaunchTimer* timer = nullptr;    // optional per-GEMV-launch event timing (instrumented bench leg): whole GEMV family
+    LaunchTimer* timer_gu = nullptr; // ... and the gate/up kernel alone (the dominant launch by bytes)
     // op-level access for parity tests
     const Q8Mat& mat_qkv(int l) const { return layers_[l].wqkv; }
     const Q8Mat& mat_out() const { return output_; }
@@ -67,7 +70,7 @@ private:
     DevBuf<int32_t> d_mrope_;
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
-    bool same_seq_ = false; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
+    bool same_seq_ = false; bool short_ctx_ = false; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
     std::map<const uint8_t*, uint8_t*> mat_meta_, mat_types_;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;

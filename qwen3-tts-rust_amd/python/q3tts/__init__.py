@@ -37,7 +37,8 @@ class Request(C.Structure):
 class Stats(C.Structure):
     _fields_ = [("frame_loop_ms", C.c_double), ("frames", C.c_int64), ("prefill_ms", C.c_double), ("gemv_ms", C.c_double),
                 ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double), ("codec_ms", C.c_double), ("codec_calls", C.c_int64),
-                ("talker_weight_bytes", C.c_double), ("predictor_weight_bytes", C.c_double), ("kv_bytes_per_token", C.c_double)]
+                ("talker_weight_bytes", C.c_double), ("predictor_weight_bytes", C.c_double), ("kv_bytes_per_token", C.c_double),
+                ("gu_ms", C.c_double), ("gu_launches", C.c_int64), ("gu_bytes", C.c_double)]
 
 
 DECODE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
