@@ -98,6 +98,12 @@ void launch_advance(hipStream_t st, const AdvanceArgs& a);
 
 void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
 
+// ---- 16/32-bit float weights (bf16 / f16 / f32 files): f32 activations, no activation quantisation (spec S3 float form:
+// 8-element fma sub-chains, block = (c0+c1)+(c2+c3), blocks added in order inside a segment, segments / super-segments in order)
+struct FMat { const void* w = nullptr; int type = 0; int N = 0, K = 0; size_t bytes() const { return (size_t)N * K * (type == 0 ? 4 : 2); } };
+void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok);
+void launch_swiglu_f32(hipStream_t st, const float* gu, int ff, float* out, int ntok);
+
 // ------------------------------- fused decode-step kernels (kernels_fused.hip) -------------------------------
 typedef unsigned long long q3_u64;
 // prologue of the fused GEMVs: h = h_in (+ parts); RMSNorm; quantise (spec S9,S4,S2)

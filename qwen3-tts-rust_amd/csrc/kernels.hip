@@ -823,6 +823,79 @@ void launch_advance(hipStream_t st, const AdvanceArgs& a) {
     hipLaunchKernelGGL(k_advance, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
 }
 
+// =====================================================================================================
+// float-weight GEMV (bf16 / f16 / f32 rows, row-major as stored in the GGUF): one wave per output row; lane l owns the
+// 8-element sub-chunks l, l+64, ... of the row (16 B of bf16 per load, 1 KiB per wave instruction); the 4 lanes of a
+// 32-block combine with two xor shuffles, the 8 block terms of a 256-segment are chained in order, segments and
+// super-segments in order (spec S3, float form).
+// =====================================================================================================
+template <int TYPE> // 0 f32, 1 f16, 30 bf16
+__device__ __forceinline__ void load8(const void* row, int e, float* v) {
+    if (TYPE == Q3_T_F32) {
+        const float4 a = *reinterpret_cast<const float4*>((const float*)row + e), b = *reinterpret_cast<const float4*>((const float*)row + e + 4);
+        v[0] = a.x; v[1] = a.y; v[2] = a.z; v[3] = a.w; v[4] = b.x; v[5] = b.y; v[6] = b.z; v[7] = b.w;
+    } else {
+        const uint4 u = *reinterpret_cast<const uint4*>((const uint16_t*)row + e);
+        const uint32_t wds[4] = { u.x, u.y, u.z, u.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if (TYPE == Q3_T_BF16) { v[2 * i] = q3_bits_f32(wds[i] << 16); v[2 * i + 1] = q3_bits_f32(wds[i] & 0xFFFF0000u); }
+            else { v[2 * i] = h2f(wds[i] & 0xFFFFu); v[2 * i + 1] = h2f(wds[i] >> 16); }
+        }
+    }
+}
+template <int TYPE>
+__global__ void __launch_bounds__(256) k_gemv_float(const void* __restrict__ w, int K, int row0, int nrows, const float* __restrict__ x,
+                                                    int x_stride, float* __restrict__ out, int out_stride) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = blockIdx.x * 4 + wave, tok = blockIdx.y;
+    if (r >= nrows) return;
+    const size_t esz = TYPE == Q3_T_F32 ? 4 : 2;
+    const char* row = (const char*)w + (size_t)(row0 + r) * K * esz;
+    const float* xv = x + (size_t)tok * x_stride;
+    const int nseg = K >> 8;
+    float y = 0.0f, S = 0.0f;
+    for (int e0 = 0; e0 < K; e0 += 512) { // one wave instruction covers 512 elements = 2 segments
+        const int e = e0 + 8 * lane;
+        float bt = 0.0f;
+        if (e < K) {
+            float wv[8];
+            load8<TYPE>(row, e, wv);
+            const float4 xa = *reinterpret_cast<const float4*>(xv + e), xb = *reinterpret_cast<const float4*>(xv + e + 4);
+            float c = 0.0f;
+            c = q3_fmaf(wv[0], xa.x, c); c = q3_fmaf(wv[1], xa.y, c); c = q3_fmaf(wv[2], xa.z, c); c = q3_fmaf(wv[3], xa.w, c);
+            c = q3_fmaf(wv[4], xb.x, c); c = q3_fmaf(wv[5], xb.y, c); c = q3_fmaf(wv[6], xb.z, c); c = q3_fmaf(wv[7], xb.w, c);
+            const float a = c + __shfl_xor(c, 1); // (c0+c1) | (c2+c3)
+            bt = a + __shfl_xor(a, 2);            // (c0+c1)+(c2+c3)
+        }
+#pragma unroll
+        for (int sg = 0; sg < 2; sg++) { // the two segments of this load: lanes [32*sg, 32*sg+32)
+            const int s = (e0 >> 8) + sg;
+            if (s < nseg) {
+                float acc = 0.0f;
+#pragma unroll
+                for (int j = 0; j < 8; j++) acc = acc + __shfl(bt, 32 * sg + 4 * j);
+                S = (s % Q3_SSEG_SEGS == 0) ? acc : S + acc;
+                if (s % Q3_SSEG_SEGS == Q3_SSEG_SEGS - 1 || s == nseg - 1) y = (s < Q3_SSEG_SEGS) ? S : y + S;
+            }
+        }
+    }
+    if (lane == 0) out[(size_t)tok * out_stride + r] = y;
+}
+void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
+    dim3 grid((nrows + 3) / 4, ntok);
+    if (w.type == Q3_T_F32) hipLaunchKernelGGL((k_gemv_float<Q3_T_F32>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
+    else if (w.type == Q3_T_F16) hipLaunchKernelGGL((k_gemv_float<Q3_T_F16>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
+    else hipLaunchKernelGGL((k_gemv_float<Q3_T_BF16>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
+}
+__global__ void k_swiglu_f32(const float* __restrict__ gu, int ff, float* __restrict__ out) {
+    const int tok = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
+    if (e < ff) out[(size_t)tok * ff + e] = q3_swiglu(gu[(size_t)tok * 2 * ff + e], gu[(size_t)tok * 2 * ff + ff + e]);
+}
+void launch_swiglu_f32(hipStream_t st, const float* gu, int ff, float* out, int ntok) {
+    hipLaunchKernelGGL(k_swiglu_f32, dim3((ff + 255) / 256, ntok), dim3(256), 0, st, gu, ff, out);
+}
+
 __global__ void k_copy_f32(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) dst[i] = src[i];

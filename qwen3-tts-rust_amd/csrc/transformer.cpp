@@ -140,6 +140,24 @@ void Transformer::load_into(const Gguf& g, const std::string& name, Q8Mat& dst, 
     Q3_HIP(hipDeviceSynchronize());
 }
 
+FMat Transformer::make_fmat(const Gguf& g, const std::vector<std::string>& names, int K_expect) {
+    FMat m;
+    size_t total = 0;
+    for (auto& n : names) {
+        const GgufTensor& t = g.need(n);
+        Q3_CHECK(t.ne[0] == K_expect && (t.type == Q3_T_F32 || t.type == Q3_T_F16 || t.type == Q3_T_BF16), "bad float tensor " + n);
+        if (m.N == 0) m.type = t.type;
+        Q3_CHECK(t.type == m.type, "mixed float types in one fused matrix: " + n);
+        m.N += (int)t.ne[1]; total += t.nbytes;
+    }
+    m.K = K_expect;
+    blobs_.emplace_back(total);
+    size_t off = 0;
+    for (auto& n : names) { const GgufTensor& t = g.need(n); Q3_HIP(hipMemcpy(blobs_.back().p + off, t.data, t.nbytes, hipMemcpyHostToDevice)); off += t.nbytes; }
+    m.w = blobs_.back().p;
+    return m;
+}
+
 float* Transformer::load_f32(const Gguf& g, const std::string& name, int64_t n_expect) {
     const GgufTensor& t = g.need(name);
     Q3_CHECK(t.type == Q3_T_F32 && t.ne[0] * t.rows() == n_expect, "bad f32 tensor " + name);
@@ -168,9 +186,27 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     Q3_CHECK(hp_.n_head * 128 <= 2048, "n_head*128 must be <= 2048 (single super-segment o-proj)");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
     layers_.resize(hp_.n_layer);
+    {
+        const int t0 = g.need("blk.0.attn_q.weight").type;
+        float_mode_ = (t0 == Q3_T_F32 || t0 == Q3_T_F16 || t0 == Q3_T_BF16);
+    }
     for (int l = 0; l < hp_.n_layer; l++) {
         Layer& L = layers_[l];
         const std::string p = "blk." + std::to_string(l) + ".";
+        if (float_mode_) { // bf16 / f16 / f32 files: rows stay as stored, activations stay f32 (spec S3 float form)
+            L.fqkv = make_fmat(g, {p + "attn_q.weight", p + "attn_k.weight", p + "attn_v.weight"}, d);
+            L.fo = make_fmat(g, {p + "attn_output.weight"}, dq);
+            L.fgu = make_fmat(g, {p + "ffn_gate.weight", p + "ffn_up.weight"}, d);
+            L.fdown = make_fmat(g, {p + "ffn_down.weight"}, ff);
+            L.attn_norm = load_f32(g, p + "attn_norm.weight", d);
+            L.q_norm = load_f32(g, p + "attn_q_norm.weight", 128);
+            L.k_norm = load_f32(g, p + "attn_k_norm.weight", 128);
+            L.ffn_norm = load_f32(g, p + "ffn_norm.weight", d);
+            const size_t lb = L.fqkv.bytes() + L.fo.bytes() + L.fgu.bytes() + L.fdown.bytes();
+            if (l == 0) layer_weight_bytes_ = lb;
+            weight_bytes_ += lb;
+            continue;
+        }
         L.wqkv = make_mat(dq + 2 * dkv, d);
         load_into(g, p + "attn_q.weight", L.wqkv, 0, d);
         load_into(g, p + "attn_k.weight", L.wqkv, dq, d);
@@ -192,8 +228,8 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     output_norm_ = load_f32(g, "output_norm.weight", d);
     const GgufTensor& ot = g.need("output.weight");
     hp_.n_vocab = (int)ot.ne[1];
-    output_ = make_mat(hp_.n_vocab, d);
-    load_into(g, "output.weight", output_, 0, d);
+    if (float_mode_) { foutput_ = make_fmat(g, {"output.weight"}, d); fused = false; }
+    else { output_ = make_mat(hp_.n_vocab, d); load_into(g, "output.weight", output_, 0, d); }
     if (!all_q8_) fused = false; // the fused decode kernels are Q8_0-only; K-quant files run the 9-launch sequence (same arithmetic)
     // RoPE tables: same double-precision expressions as the oracle (spec S5)
     std::vector<float> c((size_t)n_ctx * 64), s((size_t)n_ctx * 64);
@@ -210,6 +246,7 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     nparts_d_ = ((ff >> 8) + 7) / 8;
     const size_t T = (size_t)max_tok;
     scratch_.alloc(T * 32); hid_.alloc(T * d); big_logits_.alloc(T * 2176);
+    if (float_mode_) { xnf_.alloc(T * d); attf_.alloc(T * dq); actf_.alloc(T * ff); }
     h_.alloc(T * d); h2_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
     qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
     const size_t mx = (size_t)(d > dq ? d : dq);
@@ -226,6 +263,7 @@ void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, cons
 void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
     Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    if (float_mode_) { last_fused_ = false; last_ntok_ = ntok; forward_float(st, in, ntok, tm, kv, hidden_out); return; }
     const bool use_fused = fused && ntok <= 8; // batched steps (ntok > 8) take the weight-stationary token-sweep GEMM path
     last_fused_ = use_fused; last_ntok_ = ntok;
     if (use_fused) {
@@ -302,10 +340,41 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     norm(f);
 }
 
+void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
+    const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    auto norm = [&](const float* h_in, int h_stride, const unsigned long long* idx_keys, int idx_stride, const float* parts, const float* g, float* xn) {
+        NormArgs a{};
+        a.h_in = h_in; a.h_stride = h_stride; a.idx_keys = idx_keys; a.idx_stride = idx_stride; a.parts = parts; a.nparts = parts ? 1 : 0; a.parts_stride = d;
+        a.h_out = h_.p; a.g = g; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p; a.xn_out = xn; // int8 copy unused in float mode
+        launch_rmsnorm_quant(st, a, ntok);
+    };
+    auto fgemv = [&](const FMat& w, const float* x, int xs, float* out, int os) {
+        if (timer) timer->begin(st);
+        launch_gemv_float(st, w, 0, w.N, x, xs, out, os, ntok);
+        if (timer) timer->end(st, (double)w.bytes());
+    };
+    for (int l = 0; l < hp_.n_layer; l++) {
+        const Layer& L = layers_[l];
+        if (l == 0) norm(in.x, in.x_stride, in.idx_keys, in.idx_stride, nullptr, L.attn_norm, xnf_.p);
+        else norm(h_.p, d, nullptr, 0, parts_d_.p, L.attn_norm, xnf_.p);
+        fgemv(L.fqkv, xnf_.p, d, qkv_.p, dq + 2 * dkv);
+        launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                              n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
+        launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, attf_.p, aq_.p, ad_.p, ntok);
+        fgemv(L.fo, attf_.p, dq, parts_o_.p, d);
+        norm(h_.p, d, nullptr, 0, parts_o_.p, L.ffn_norm, xnf_.p);
+        fgemv(L.fgu, xnf_.p, d, gu_.p, 2 * ff);
+        launch_swiglu_f32(st, gu_.p, ff, actf_.p, ntok);
+        fgemv(L.fdown, actf_.p, ff, parts_d_.p, d);
+    }
+    norm(h_.p, d, nullptr, 0, parts_d_.p, output_norm_, hidden_out ? hidden_out : hid_.p);
+    if (hidden_out) launch_copy_f32(st, hidden_out, hid_.p, (size_t)ntok * d);
+}
+
 void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
                        const ArgmaxEpi* am, int nrows_valid, float* hidden_out) {
     const int d = hp_.n_embd;
-    Q3_CHECK(row0 % 32 == 0 && row0 + nrows <= output_.Npad, "head row range");
+    Q3_CHECK(row0 % 32 == 0 && (float_mode_ || row0 + nrows <= output_.Npad), "head row range");
     if (last_fused_) {
         // final RMSNorm (+ last down-proj partials + residual) as the prologue of the output-matrix GEMV
         NormPro f{};
@@ -327,6 +396,15 @@ void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nr
     }
     if (hidden_out) launch_copy_f32(st, hid_.p + (size_t)tok0 * d, hidden_out, (size_t)tok_count * d);
     if (nrows <= 0) return;
+    if (float_mode_) {
+        float* dst = am ? big_logits_.p : logits;
+        const int ls = am ? nrows : logits_stride;
+        if (timer) timer->begin(st);
+        launch_gemv_float(st, foutput_, row0, nrows, hid_.p + (size_t)tok0 * d, d, dst, ls, tok_count);
+        if (timer) timer->end(st, (double)nrows * d * (foutput_.type == Q3_T_F32 ? 4 : 2));
+        if (am) launch_argmax_keys(st, big_logits_.p, nrows, nrows_valid > 0 ? nrows_valid : nrows, am->mask_per_tok, am->keys, am->key_stride, tok_count);
+        return;
+    }
     if (am) { // batched-step path: logits to scratch, then argmax keys
         const int nv = nrows_valid > 0 ? nrows_valid : nrows;
         if (big_logits_.n < (size_t)tok_count * nrows) throw Error("head scratch too small");

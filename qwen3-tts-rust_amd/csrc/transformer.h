@@ -51,7 +51,10 @@ public:
     const Q8Mat& mat_out() const { return output_; }
 
 private:
-    struct Layer { Q8Mat wqkv, wo, wgu, wdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
+    struct Layer { Q8Mat wqkv, wo, wgu, wdown; FMat fqkv, fo, fgu, fdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
+    FMat make_fmat(const Gguf& g, const std::vector<std::string>& names, int K_expect);
+    void forward_float(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out);
+    bool float_mode_ = false; FMat foutput_; DevBuf<float> xnf_, attf_, actf_;
     float* scratch_logits(int) { return scratch_.p; }
     DevBuf<float> scratch_, hid_, big_logits_;
     void gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,

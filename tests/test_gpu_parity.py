@@ -208,6 +208,23 @@ def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     ge.close(); oe.close()
 
 
+def test_bf16_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
+    """BASELINE.json configs[4] weight type (bf16): f32 activations, float-weight GEMV (spec S3 float form), bit-exact tokens."""
+    qdir = os.path.join(tiny_model, "gguf_bf16")
+    for name, d, npre in (("qwen3_tts_talker.gguf", 2048, 19), ("qwen3_tts_predictor.gguf", 256, 2)):
+        _tf_parity(gpu, oracle, os.path.join(qdir, name), d, npre, 4, 2048)
+    ge = gpu.Engine(tiny_model, "bf16", max_batch=2, max_steps=32, load_codec=False)
+    oe = oracle.Engine(qdir, None, 4)
+    rng = np.random.default_rng(21)
+    prompts = [ge.assets.build_core(np.arange(100, 109, dtype=np.int32), lang_id=2055, spk_emb=vivian),
+               ge.assets.build_clone(rng.integers(0, 4000, 5).astype(np.int32), rng.integers(0, 2048, 3 * 16), rng.integers(0, 4000, 2), vivian)]
+    res = ge.generate_batch(prompts, max_steps=8, mask_eos=True)
+    for p, r in zip(prompts, res):
+        oc, _ = oe.generate(p, max_steps=8, mask_eos=True)
+        assert np.array_equal(oc, r["codes"])
+    ge.close(); oe.close()
+
+
 def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
     path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
     rng = np.random.default_rng(8)
