@@ -196,40 +196,58 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
         std::vector<q3_u64> k0((size_t)16 * W, pack_key(-INFINITY, 0)), n0(W, pack_key(-INFINITY, 0));
         d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
     }
-    // ---------------- prefill, one sequence at a time (engine.rs:455-462) ----------------
-    for (int b = 0; b < B; b++) {
-        const GenRequest& r = reqs[b];
-        Q3_CHECK(r.n_prompt >= 1 && r.n_prompt <= p_.max_prompt, "prompt length out of range");
-        Q3_CHECK(r.max_steps >= 0 && r.max_steps <= p_.max_steps, "max_steps out of range");
-        kv_t_->release(b);
-        kv_t_->ensure(b, r.n_prompt + r.max_steps + 1);
-        Q3_HIP(hipMemcpyAsync(d_prompt_.p, r.prompt, (size_t)r.n_prompt * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
+    // ---------------- prefill (engine.rs:455-462): all prompts as ONE token stream, chunked by the talker's launch width ----------------
+    // tokens of different sequences share a launch (per-token seq/slot/pos routing); each sequence's last token gets the head.
+    {
+        size_t total = 0;
+        for (int b = 0; b < B; b++) {
+            const GenRequest& r = reqs[b];
+            Q3_CHECK(r.n_prompt >= 1 && r.n_prompt <= p_.max_prompt, "prompt length out of range");
+            Q3_CHECK(r.max_steps >= 0 && r.max_steps <= p_.max_steps, "max_steps out of range");
+            kv_t_->release(b);
+            kv_t_->ensure(b, r.n_prompt + r.max_steps + 1);
+            total += (size_t)r.n_prompt;
+            maxf[b] = r.max_steps; fin[b] = 0;
+            tslot[b] = r.n_prompt; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = r.n_prompt;
+            max_steps_all = std::max(max_steps_all, r.max_steps);
+            if (r.sampler.temperature > 0.0f) any_sampled = true;
+        }
         const int chunk = talker_->max_tok();
-        for (int t0c = 0; t0c < r.n_prompt; t0c += chunk) {
-            const int n = std::min(chunk, r.n_prompt - t0c);
-            std::vector<int32_t> seq(n, b), slot(n), pos((size_t)4 * n);
-            for (int i = 0; i < n; i++) { slot[i] = t0c + i; pos[4 * i] = pos[4 * i + 1] = pos[4 * i + 2] = t0c + i; pos[4 * i + 3] = 0; } // :306-314
-            Q3_HIP(hipMemcpyAsync(d_pf_seq_.p, seq.data(), n * 4, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipMemcpyAsync(d_pf_slot_.p, slot.data(), n * 4, hipMemcpyHostToDevice, st_));
+        if (d_prompt_.n < (size_t)chunk * Q3_EMBD) d_prompt_.alloc((size_t)chunk * Q3_EMBD);
+        std::vector<float> stage((size_t)chunk * Q3_EMBD);
+        std::vector<int32_t> seq(chunk), slot(chunk), pos((size_t)4 * chunk);
+        int b = 0, t = 0; // cursor over (sequence, token)
+        size_t done = 0;
+        talker_->set_same_seq_tokens(true);
+        while (done < total) {
+            int n = 0;
+            std::vector<std::pair<int, int>> lasts; // (sequence, index inside this chunk) of final prompt tokens
+            while (n < chunk && b < B) {
+                const GenRequest& r = reqs[b];
+                std::copy(r.prompt + (size_t)t * Q3_EMBD, r.prompt + (size_t)(t + 1) * Q3_EMBD, stage.begin() + (size_t)n * Q3_EMBD);
+                seq[n] = b; slot[n] = t; pos[4 * n] = pos[4 * n + 1] = pos[4 * n + 2] = t; pos[4 * n + 3] = 0; // :306-314
+                if (t == r.n_prompt - 1) { lasts.emplace_back(b, n); b++; t = 0; } else t++;
+                n++;
+            }
+            Q3_HIP(hipMemcpyAsync(d_prompt_.p, stage.data(), (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
+            Q3_HIP(hipMemcpyAsync(d_pf_seq_.p, seq.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
+            Q3_HIP(hipMemcpyAsync(d_pf_slot_.p, slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
             Q3_HIP(hipMemcpyAsync(d_pf_pos_.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipStreamSynchronize(st_)); // host vectors go out of scope
+            Q3_HIP(hipStreamSynchronize(st_)); // staging vectors are reused by the next chunk
             TokMeta tm{d_pf_seq_.p, d_pf_slot_.p, d_pf_pos_.p};
-            Transformer::Input in; in.x = d_prompt_.p + (size_t)t0c * Q3_EMBD; in.x_stride = Q3_EMBD;
-            talker_->set_same_seq_tokens(true);
+            Transformer::Input in; in.x = d_prompt_.p; in.x_stride = Q3_EMBD;
             talker_->forward(st_, in, n, tm, kv_t_->view(), nullptr);
-            if (t0c + n == r.n_prompt) { // logits / code_0 + hidden of the LAST prompt token (engine.rs:550-554,565-566)
-                if (r.sampler.temperature > 0.0f || any_sampled_req)
-                    talker_->head(st_, n - 1, 1, 0, tl_stride_, d_tlogits_.p + (size_t)b * tl_stride_, tl_stride_, nullptr, -1, d_thidden_.p + (size_t)b * Q3_EMBD);
+            for (auto& lb : lasts) { // logits / code_0 + hidden of the LAST prompt token (engine.rs:550-554,565-566)
+                const int sb = lb.first, ti = lb.second;
+                if (any_sampled_req)
+                    talker_->head(st_, ti, 1, 0, tl_stride_, d_tlogits_.p + (size_t)sb * tl_stride_, tl_stride_, nullptr, -1, d_thidden_.p + (size_t)sb * Q3_EMBD);
                 else {
-                    ArgmaxEpi am{d_keys_.p + (size_t)b * 16, 16, d_maskeos_.p + b, 0};
-                    talker_->head(st_, n - 1, 1, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p + (size_t)b * Q3_EMBD);
+                    ArgmaxEpi am{d_keys_.p + (size_t)sb * 16, 16, d_maskeos_.p + sb, 0};
+                    talker_->head(st_, ti, 1, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p + (size_t)sb * Q3_EMBD);
                 }
             }
+            done += (size_t)n;
         }
-        maxf[b] = r.max_steps; fin[b] = 0;
-        tslot[b] = r.n_prompt; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = r.n_prompt;
-        max_steps_all = std::max(max_steps_all, r.max_steps);
-        if (r.sampler.temperature > 0.0f) any_sampled = true;
     }
     for (int b = B; b < W; b++) { tslot[b] = 0; } // idle slots write to their single reserved page
     d_maxframes_.upload(maxf.data(), W); d_finished_.upload(fin.data(), W);
