@@ -197,11 +197,16 @@ def main():
                          "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
                          "avg_launch_us": 1e3 * si["gu_ms"] / max(si["gu_launches"], 1),
                          "bytes_per_launch": si["gu_bytes"] / max(si["gu_launches"], 1),
-                         "traffic": 27.09e6,  # profiles/r01_hbm_traffic_pmc.md: FETCH_SIZE 13230 KiB x 2 (gfx950 correction) per launch
+                         "traffic": 27.04e6,  # profiles/r01_hbm_traffic_pmc.md: FETCH_SIZE 13202 KiB x 2 (gfx950 correction) per launch
                          "method": "HIP-event pair around every launch in an eager replay of the same K steps (adds ~1-2 us over rocprof's kernel time)",
                          "family_all_gemv": {"achieved": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS, "launches": fam_n,
                                              "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1)}},
         }
+        if args.batch > 1:
+            # batched steps run the weight-streaming GEMM kernels (k_gemm_q8_mfma / k_gemm_q8_tok); the instrumented family is the line
+            out["roofline"].update({"kernel": "q3::k_gemm_q8_mfma + k_gemv_q8* family (batched step; %d launches)" % fam_n, "achieved": gemv_gbs,
+                                    "frac": gemv_gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1),
+                                    "bytes_per_launch": fam_bytes / max(fam_n, 1), "traffic": None})
         log("instrumented leg done")
         if world == 1 and not args.no_cpu_baseline:
             try:
