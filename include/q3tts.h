@@ -80,11 +80,46 @@ typedef struct q3tts_stats {
     double codec_ms; int64_t codec_calls;
     double talker_weight_bytes, predictor_weight_bytes, kv_bytes_per_token;
     double gu_ms; int64_t gu_launches; double gu_bytes;       /* talker gate/up kernel alone (instrumented leg) */
+    int64_t sched_steps; double slot_frames;                  /* scheduler: frame groups launched, sum of graph width x frames */
 } q3tts_stats;
 int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* out);
 void q3tts_engine_reset_stats(q3tts_engine* e);
 void q3tts_engine_set_instrument(q3tts_engine* e, int32_t on);
 double q3tts_engine_bytes_per_step(q3tts_engine* e, int32_t batch, double mean_ctx);
+
+/* ---- continuous-batching scheduler (SURVEY 8b "q3tts_submit / q3tts_poll"; BASELINE config 3) ----
+ * Requests queue up and are admitted into the engine's max_batch sequence slots as slots free up; every slot advances
+ * one frame per graph replay; finished sequences retire on EOS (engine.rs:558-561) or max_steps.  Results are identical
+ * to running each request alone (the arithmetic is batch-invariant).  Either call q3tts_sched_start once (background
+ * driver thread) or drive it yourself with q3tts_sched_step / q3tts_wait.  q3tts_generate_batch is submit-all + wait-all. */
+#define Q3TTS_REQ_QUEUED 0
+#define Q3TTS_REQ_RUNNING 1
+#define Q3TTS_REQ_DRAINING 2 /* all frames generated, codec still decoding the tail */
+#define Q3TTS_REQ_DONE 3
+#define Q3TTS_REQ_FAILED (-1)
+typedef struct q3tts_req_status {
+    int32_t state; int32_t n_frames; int64_t n_pcm; /* frames emitted / PCM samples decoded so far (streamable) */
+    double queue_ms, prefill_ms, first_chunk_ms, total_ms;
+} q3tts_req_status;
+/* r->prompt/n_prompt/sampler/max_steps/mask_eos are read (the prompt is copied); output fields of r are ignored */
+int q3tts_submit(q3tts_engine* e, const q3tts_request* r, int32_t want_pcm, int64_t* req_id);
+int q3tts_poll(q3tts_engine* e, int64_t req_id, q3tts_req_status* out);
+/* streaming read: frames [frame_off, frame_off+max_frames) and PCM [pcm_off, pcm_off+pcm_cap) available right now */
+int q3tts_fetch(q3tts_engine* e, int64_t req_id, int32_t* codes_out, int32_t frame_off, int32_t max_frames, float* pcm_out,
+                int64_t pcm_off, int64_t pcm_cap, int32_t* got_frames, int64_t* got_pcm);
+int q3tts_wait(q3tts_engine* e, int64_t req_id, double timeout_ms /* <0: forever */); /* 0 done, 1 timeout, <0 error */
+int q3tts_release(q3tts_engine* e, int64_t req_id);
+int q3tts_sched_start(q3tts_engine* e);
+int q3tts_sched_stop(q3tts_engine* e);
+int q3tts_sched_step(q3tts_engine* e, int32_t* busy);
+/* voices: the engine-side analogue of VoiceFile (utils/voice_file.rs:5-22).  ref_codes [n_ref_frames*16] / ref_text_ids may be
+ * NULL for preset voices.  In multi-GPU serving the owning rank broadcasts these arrays first (q3tts.dist.broadcast_voice). */
+int q3tts_voice_register(q3tts_engine* e, const float* spk_emb2048, const int32_t* ref_codes, int32_t n_ref_codes,
+                         const int32_t* ref_text_ids, int32_t n_ref_text, int32_t* voice_id);
+/* generate_with_voice_ids (engine.rs:390-435): builds the preset or clone prompt from the voice + token ids, then submits */
+int q3tts_submit_text(q3tts_engine* e, int32_t voice_id, const int32_t* text_ids, int32_t n_text, int32_t lang_id,
+                      const int32_t* instr_ids, int32_t n_instr, const q3tts_sampler_config* sampler, int32_t max_steps,
+                      int32_t mask_eos, int32_t want_pcm, int64_t* req_id);
 
 /* ---- assets + prompt builder (host) ---- */
 typedef struct q3tts_assets q3tts_assets;
@@ -147,6 +182,9 @@ int q3tts_op_rmsnorm_quant(const float* x, const float* g, int32_t d, int32_t nt
                            float* xn);
 int q3tts_op_swiglu_quant(const float* gu, int32_t ff, int32_t ntok, int8_t* aq, uint16_t* ad);
 int q3tts_op_argmax(const float* logits, int32_t n, int32_t start, int32_t end, int32_t mask_idx, int32_t* out);
+/* device sampler (llama/mod.rs:666-776): n_draws consecutive draws of one seeded sequence over logits[0,n), n <= 4096 */
+int q3tts_op_sample(const float* logits, int32_t n, float temperature, int32_t top_k, float top_p, uint64_t seed, int32_t mask_idx,
+                    int32_t n_draws, int32_t* out);
 int q3tts_op_project(const float* x, const float* w /* [n_out][n_in] */, const float* b, int32_t n_in, int32_t n_out, float* y);
 
 #ifdef __cplusplus

@@ -148,7 +148,7 @@ int32_t q3o_sample(q3o_sampler* s, const float* logits, int n_vocab, int start, 
     if (s->top_k > 0 && s->top_k < n) n = s->top_k;
     float max_logit = c[0].v;
     float sum = 0.0f;
-    for (int i = 0; i < n; i++) { float sc = (c[i].v - max_logit) / s->temperature; c[i].v = expf(sc); sum += c[i].v; }
+    for (int i = 0; i < n; i++) { float sc = (c[i].v - max_logit) / s->temperature; c[i].v = q3_expf(sc); sum += c[i].v; }
     if (sum > 0.0f) for (int i = 0; i < n; i++) c[i].v /= sum;
     if (s->top_p < 1.0f) {
         float cum = 0.0f;

@@ -6,7 +6,7 @@ ARCH=${Q3_ARCH:-gfx950}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
 mkdir -p build
 OBJS=""
-for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/llama_shim.cpp; do
+for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/llama_shim.cpp; do
   [ -f "$f" ] || continue
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then

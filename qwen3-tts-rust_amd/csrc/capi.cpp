@@ -49,15 +49,12 @@ int q3tts_engine_create(const q3tts_engine_params* p, q3tts_engine** out) {
 }
 void q3tts_engine_destroy(q3tts_engine* e) { delete e; }
 
+static GenRequest to_gen(const q3tts_request& q);
 int q3tts_generate_batch(q3tts_engine* e, q3tts_request* reqs, int32_t n, int32_t want_pcm) {
     Q3_API_BEGIN
     Q3_CHECK(e && reqs && n >= 1, "bad arguments");
     std::vector<GenRequest> rq(n);
-    for (int i = 0; i < n; i++) {
-        rq[i].prompt = reqs[i].prompt; rq[i].n_prompt = reqs[i].n_prompt; rq[i].max_steps = reqs[i].max_steps; rq[i].mask_eos = reqs[i].mask_eos != 0;
-        rq[i].sampler.temperature = reqs[i].sampler.temperature; rq[i].sampler.top_k = reqs[i].sampler.top_k; rq[i].sampler.top_p = reqs[i].sampler.top_p;
-        rq[i].sampler.has_seed = reqs[i].sampler.has_seed != 0; rq[i].sampler.seed = reqs[i].sampler.seed;
-    }
+    for (int i = 0; i < n; i++) rq[i] = to_gen(reqs[i]);
     std::vector<GenResult> res;
     e->e->generate_batch(rq, res, want_pcm != 0);
     for (int i = 0; i < n; i++) {
@@ -72,12 +69,100 @@ int q3tts_generate_batch(q3tts_engine* e, q3tts_request* reqs, int32_t n, int32_
     Q3_API_END(Q3TTS_ERR)
 }
 
+static GenRequest to_gen(const q3tts_request& q) {
+    GenRequest g;
+    g.prompt = q.prompt; g.n_prompt = q.n_prompt; g.max_steps = q.max_steps; g.mask_eos = q.mask_eos != 0;
+    g.sampler.temperature = q.sampler.temperature; g.sampler.top_k = q.sampler.top_k; g.sampler.top_p = q.sampler.top_p;
+    g.sampler.has_seed = q.sampler.has_seed != 0; g.sampler.seed = q.sampler.seed;
+    return g;
+}
+int q3tts_submit(q3tts_engine* e, const q3tts_request* r, int32_t want_pcm, int64_t* req_id) {
+    Q3_API_BEGIN
+    Q3_CHECK(e && r && req_id, "null argument");
+    *req_id = e->e->submit(to_gen(*r), want_pcm != 0, true);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_poll(q3tts_engine* e, int64_t id, q3tts_req_status* o) {
+    Q3_API_BEGIN
+    Q3_CHECK(e && o, "null argument");
+    const ReqStatus s = e->e->poll(id);
+    o->state = s.state; o->n_frames = s.n_frames; o->n_pcm = s.n_pcm; o->queue_ms = s.queue_ms; o->prefill_ms = s.prefill_ms;
+    o->first_chunk_ms = s.first_chunk_ms; o->total_ms = s.total_ms;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_fetch(q3tts_engine* e, int64_t id, int32_t* codes, int32_t frame_off, int32_t max_frames, float* pcm, int64_t pcm_off,
+                int64_t pcm_cap, int32_t* got_frames, int64_t* got_pcm) {
+    Q3_API_BEGIN
+    Q3_CHECK(e, "null argument");
+    int gf = 0; int64_t gp = 0;
+    e->e->fetch(id, codes, frame_off, max_frames, pcm, pcm_off, pcm_cap, &gf, &gp);
+    if (got_frames) *got_frames = gf;
+    if (got_pcm) *got_pcm = gp;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_wait(q3tts_engine* e, int64_t id, double timeout_ms) {
+    Q3_API_BEGIN
+    Q3_CHECK(e, "null argument");
+    return e->e->wait(id, timeout_ms) ? 0 : 1;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_release(q3tts_engine* e, int64_t id) { Q3_API_BEGIN Q3_CHECK(e, "null argument"); e->e->release(id); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
+int q3tts_sched_start(q3tts_engine* e) { Q3_API_BEGIN Q3_CHECK(e, "null argument"); e->e->start_driver(); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
+int q3tts_sched_stop(q3tts_engine* e) { Q3_API_BEGIN Q3_CHECK(e, "null argument"); e->e->stop_driver(); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
+int q3tts_sched_step(q3tts_engine* e, int32_t* busy) {
+    Q3_API_BEGIN
+    Q3_CHECK(e, "null argument");
+    const bool b = e->e->step();
+    if (busy) *busy = b ? 1 : 0;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_voice_register(q3tts_engine* e, const float* spk, const int32_t* ref_codes, int32_t n_ref_codes, const int32_t* ref_text,
+                         int32_t n_ref_text, int32_t* voice_id) {
+    Q3_API_BEGIN
+    Q3_CHECK(e && spk && voice_id, "null argument");
+    Voice v;
+    v.spk_emb.assign(spk, spk + 2048);
+    if (ref_codes && n_ref_codes > 0) v.ref_codes.assign(ref_codes, ref_codes + n_ref_codes);
+    if (ref_text && n_ref_text > 0) v.ref_text_ids.assign(ref_text, ref_text + n_ref_text);
+    *voice_id = e->e->register_voice(v);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_submit_text(q3tts_engine* e, int32_t voice_id, const int32_t* text_ids, int32_t n_text, int32_t lang_id, const int32_t* instr_ids,
+                      int32_t n_instr, const q3tts_sampler_config* sampler, int32_t max_steps, int32_t mask_eos, int32_t want_pcm,
+                      int64_t* req_id) {
+    Q3_API_BEGIN
+    Q3_CHECK(e && text_ids && n_text >= 0 && req_id, "bad arguments");
+    const Voice& v = e->e->voice(voice_id);
+    std::vector<int32_t> t(text_ids, text_ids + n_text), ins;
+    if (instr_ids) ins.assign(instr_ids, instr_ids + n_instr);
+    int lang = lang_id;
+    // engine.rs:398-428: clone voices (codes + ref text) take build_clone_prompt, presets build_core with marker + spk_emb
+    PromptData pd = !v.ref_codes.empty()
+        ? PromptBuilder::build_clone_prompt(e->e->assets(), t, v.ref_codes, v.ref_text_ids, v.spk_emb.data(), lang_id, instr_ids ? &ins : nullptr)
+        : PromptBuilder::build_core(e->e->assets(), t, lang_id >= 0 ? &lang : nullptr, nullptr, v.spk_emb.data(), instr_ids ? &ins : nullptr, nullptr);
+    GenRequest g;
+    g.prompt = pd.embd.data(); g.n_prompt = pd.n_rows; g.max_steps = max_steps; g.mask_eos = mask_eos != 0;
+    if (sampler) {
+        g.sampler.temperature = sampler->temperature; g.sampler.top_k = sampler->top_k; g.sampler.top_p = sampler->top_p;
+        g.sampler.has_seed = sampler->has_seed != 0; g.sampler.seed = sampler->seed;
+    }
+    *req_id = e->e->submit(g, want_pcm != 0, true);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
 int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* o) {
     Q3_API_BEGIN
     const EngineStats& s = e->e->stats;
     o->frame_loop_ms = s.frame_loop_ms; o->frames = s.frames; o->prefill_ms = s.prefill_ms; o->gemv_ms = s.gemv_ms;
     o->gemv_launches = s.gemv_launches; o->gemv_bytes = s.gemv_bytes; o->codec_ms = s.codec_ms; o->codec_calls = s.codec_calls;
     o->gu_ms = s.gu_ms; o->gu_launches = s.gu_launches; o->gu_bytes = s.gu_bytes;
+    o->sched_steps = s.steps; o->slot_frames = s.slot_frames;
     o->talker_weight_bytes = (double)e->e->talker().weight_bytes(); o->predictor_weight_bytes = (double)e->e->predictor().weight_bytes();
     const auto& hp = e->e->talker().hp();
     o->kv_bytes_per_token = (double)hp.n_layer * 2 * hp.n_kv * 128 * 2;

@@ -1,6 +1,7 @@
 // capi_ops.cpp -- kernel-level C-ABI entry points for the parity tests (host buffers in, host buffers out).
 #include "../../include/q3tts.h"
 #include "transformer.h"
+#include "host_logic.h"
 
 using namespace q3;
 #define Q3_API_BEGIN try {
@@ -74,6 +75,29 @@ int q3tts_op_argmax(const float* logits, int32_t n, int32_t start, int32_t end, 
     launch_argmax(0, dl.p, n, start, end, dm.p, dout.p, 1, 0, 1);
     Q3_HIP(hipDeviceSynchronize());
     dout.download(out, 1);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
+/* n_draws consecutive samples of one sequence from the SAME logits (the RNG stream advances between draws) */
+int q3tts_op_sample(const float* logits, int32_t n, float temperature, int32_t top_k, float top_p, uint64_t seed, int32_t mask_idx,
+                    int32_t n_draws, int32_t* out) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(logits && out && n >= 1 && n_draws >= 1, "bad arguments");
+    StdRng rng(seed);
+    DevBuf<float> dl(n), dt(1), dp(1); DevBuf<int32_t> dk(1), dm(1); DevBuf<uint32_t> dkey(8), ddraw(1); DevBuf<q3_u64> dout(n_draws);
+    const uint32_t zero = 0;
+    dl.upload(logits, n); dt.upload(&temperature, 1); dp.upload(&top_p, 1); dk.upload(&top_k, 1); dm.upload(&mask_idx, 1);
+    dkey.upload(rng.key(), 8); ddraw.upload(&zero, 1);
+    for (int i = 0; i < n_draws; i++) {
+        SampleArgs a{dl.p, n, n, dt.p, dk.p, dp.p, dm.p, dkey.p, ddraw.p, dout.p + i, 1};
+        launch_sample(0, a, 1);
+    }
+    Q3_HIP(hipDeviceSynchronize());
+    std::vector<q3_u64> keys(n_draws);
+    dout.download(keys.data(), n_draws);
+    for (int i = 0; i < n_draws; i++) out[i] = (int32_t)(~(uint32_t)(keys[i] & 0xFFFFFFFFull));
     return Q3TTS_OK;
     Q3_API_END(Q3TTS_ERR)
 }

@@ -7,6 +7,7 @@
 #include <mutex>
 #include <thread>
 #include "kdev.h"
+#include <functional>
 
 namespace q3 {
 
@@ -70,46 +71,77 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     kv_t_.reset(new KvPool(talker_->hp().n_layer, talker_->hp().n_kv, B * pages_per_seq, B, pages_per_seq));
     kv_p_.reset(new KvPool(predictor_->hp().n_layer, predictor_->hp().n_kv, B, B, 1));
     for (int b = 0; b < B; b++) { kv_p_->ensure(b, 16); kv_t_->ensure(b, 1); }
-    // ---- per-sequence state ----
+    // ---- per-slot state ----
     hist_stride_ = p.max_steps * 16;
     tl_stride_ = (Q3_SAMPLE_END + 31) & ~31;
     d_tseq_.alloc(B); d_tslot_.alloc(B); d_tpos_.alloc(4 * B); d_keys_.alloc(16 * B); d_next_key0_.alloc(B); d_nframes_.alloc(B); d_finished_.alloc(B);
     d_maxframes_.alloc(B); d_maskeos_.alloc(B); d_hist_.alloc((size_t)B * hist_stride_);
+    d_temp_.alloc(B); d_topp_.alloc(B); d_topk_.alloc(B); d_rngkey_.alloc((size_t)8 * B); d_draws_.alloc(B);
+    d_temp_.zero(); d_topp_.zero(); d_topk_.zero(); d_rngkey_.zero(); d_draws_.zero();
     d_tlogits_.alloc((size_t)B * tl_stride_); d_thidden_.alloc((size_t)B * Q3_EMBD); d_pin_.alloc((size_t)2 * B * dP_);
-    d_plogits_.alloc((size_t)B * Q3_CODEBOOK_SIZE); d_fb_.alloc((size_t)B * Q3_EMBD);
-    d_prompt_.alloc((size_t)p.max_prompt * Q3_EMBD); d_hid_all_.alloc((size_t)talker_->max_tok() * Q3_EMBD);
+    d_fb_.alloc((size_t)B * Q3_EMBD);
+    d_prompt_.alloc((size_t)talker_->max_tok() * Q3_EMBD);
     d_pf_seq_.alloc(talker_->max_tok()); d_pf_slot_.alloc(talker_->max_tok()); d_pf_pos_.alloc(4 * (size_t)talker_->max_tok());
     d_hist_.zero(); d_tlogits_.zero(); d_thidden_.zero();
-    // predictor routing: pass i (i = 1..15) handles position i for every sequence; pass A = positions 0 and 1 (2B tokens)
-    std::vector<int32_t> seq(B), slot((size_t)16 * B), pos((size_t)16 * B * 4), seqA(2 * B), slotA(2 * B), posA((size_t)2 * B * 4);
+    // predictor routing: pass i (i = 2..15) handles position i of every slot; tables are [16][B] so any graph width can use them
+    std::vector<int32_t> seq(B), slot((size_t)16 * B), pos((size_t)16 * B * 4);
     for (int b = 0; b < B; b++) {
         seq[b] = b;
         for (int i = 0; i < 16; i++) { slot[(size_t)i * B + b] = i; for (int s = 0; s < 4; s++) pos[((size_t)i * B + b) * 4 + s] = i; } // engine.rs:316-318
-        seqA[b] = b; seqA[B + b] = b; slotA[b] = 0; slotA[B + b] = 1;
-        for (int s = 0; s < 4; s++) { posA[(size_t)b * 4 + s] = 0; posA[((size_t)B + b) * 4 + s] = 1; }
     }
     d_pseq_.alloc(B); d_pseq_.upload(seq.data(), B);
     d_pslot_.alloc(slot.size()); d_pslot_.upload(slot.data(), slot.size());
     d_ppos_.alloc(pos.size()); d_ppos_.upload(pos.data(), pos.size());
-    d_pseqA_.alloc(2 * B); d_pseqA_.upload(seqA.data(), 2 * B);
-    d_pslotA_.alloc(2 * B); d_pslotA_.upload(slotA.data(), 2 * B);
-    d_pposA_.alloc(posA.size()); d_pposA_.upload(posA.data(), posA.size());
     d_tseq_.upload(seq.data(), B);
+    h_maxf_.assign(B, 0); h_fin_.assign(B, 1); h_nfr_.assign(B, 0); h_mask_.assign(B, -1); h_nprompt_.assign(B, 0); h_topk_.assign(B, 0);
+    h_temp_.assign(B, 0.0f); h_topp_.assign(B, 1.0f);
+    slot_req_.assign(B, nullptr);
+    {
+        std::vector<q3_u64> k0((size_t)16 * B, pack_key(-INFINITY, 0)), n0(B, pack_key(-INFINITY, 0));
+        d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
+    }
+    upload_slot_state();
     if (p.load_codec) {
-        const int n_lanes = std::min(B, 8);
-        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", B, 4, n_lanes));
+        // codec streams outnumber the slots: a retired sequence's last chunks still drain while its slot is already reused
+        const int n_cs = B + std::min(B, 16), n_lanes = std::min(B, 8);
+        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes));
         st2_.resize(n_lanes);
         for (auto& s2 : st2_) Q3_HIP(hipStreamCreate(&s2));
-        pcm_pinned_cap_ = (size_t)B * p.max_steps * codec_->samples_per_frame();
-        Q3_HIP(hipHostMalloc((void**)&pcm_pinned_, pcm_pinned_cap_ * sizeof(float)));
+        slot_cap_ = (size_t)p.max_steps * codec_->samples_per_frame();
+        Q3_HIP(hipHostMalloc((void**)&pcm_pinned_, (size_t)n_cs * slot_cap_ * sizeof(float)));
+        for (int c = n_cs - 1; c >= 0; c--) cs_free_.push_back(c);
     }
     Q3_HIP(hipStreamSynchronize(st_));
 }
 
+// ---------------------------------------------------------------------------------------------------------------
+struct Engine::Req {
+    int64_t id = 0;
+    GenRequest r; std::vector<float> prompt_own; bool want_pcm = false;
+    int state = REQ_QUEUED; int slot = -1, cs = -1; int fed = 0;
+    std::vector<int32_t> codes; std::vector<float> pcm;
+    size_t pcm_enq = 0;   // samples enqueued by the decoder thread (its private cursor)
+    size_t pcm_ready = 0; // samples whose decode has completed (harvested events)
+    std::unique_ptr<Chunker> chunker;
+    uint64_t seed = 0;
+    hipEvent_t ev_admit = nullptr; bool first_seen = false;
+    double t_submit = 0, t_admit = 0, t_done = 0, prefill_ms = 0, first_chunk_ms = 0;
+    std::string error;
+};
+
 Engine::~Engine() {
-    if (graph_exec_) (void)hipGraphExecDestroy(graph_exec_);
-    if (graph_) (void)hipGraphDestroy(graph_);
-    for (auto e : ev_pool_) (void)hipEventDestroy(e);
+    try { stop_driver(); } catch (...) {}
+    if (dec_started_) {
+        { std::lock_guard<std::mutex> lk(dmu_); dec_stop_ = true; }
+        dcv_.notify_all();
+        dec_thread_.join();
+    }
+    for (auto& c : comp_) (void)hipEventDestroy(c.ev);
+    for (auto& kv : reqs_) if (kv.second->ev_admit) (void)hipEventDestroy(kv.second->ev_admit);
+    for (auto& g : graphs_) {
+        if (g.second->exec) (void)hipGraphExecDestroy(g.second->exec);
+        if (g.second->graph) (void)hipGraphDestroy(g.second->graph);
+    }
     if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
     for (auto s2 : st2_) (void)hipStreamDestroy(s2);
     if (st_) (void)hipStreamDestroy(st_);
@@ -125,15 +157,16 @@ size_t Engine::bytes_per_frame_step(int batch, double mean_ctx) const {
            (size_t)((double)batch * mean_ctx * (double)kv_per_tok) + (size_t)batch * 17 * 8192;
 }
 
-// One frame for B lock-stepped sequences (engine.rs:545-641).  code_0 of the frame is already in keys[b][0]: it was
-// produced by the argmax epilogue of the talker head that ended the previous frame (or the prefill), or by the host sampler.
-void Engine::record_frame(int B) {
+// One frame for fg.width slots (engine.rs:545-641).  code_0 of the frame is already in keys[b][0]: it was produced at the end
+// of the previous frame (or of the prefill) by the talker head's argmax epilogue or by the device sampler.
+void Engine::record_frame(FrameGraph& fg, bool sampled) {
+    const int B = fg.width;
     const KvCache kvt = kv_t_->view(), kvp = kv_p_->view();
     // :565-573 predictor input = [project(m_hidden) ; project(E_0[code_0])]
     launch_project_blk(st_, d_thidden_.p, Q3_EMBD, d_proj_wblk_.p, d_proj_b_.p, Q3_EMBD, dP_, d_pin_.p, dP_, B);
     launch_gather_rows_keys(st_, d_proj_tab_[0].p, assets_->codec_rows[0], d_keys_.p, 16, dP_, d_pin_.p + (size_t)B * dP_, B);
     {   // :575-582 clear KV (= positions restart at 0) + 2-token prefill; :588-596 only slice q-1 of the 30720 logits is needed
-        TokMeta tm{d_pseqA_.p, d_pslotA_.p, d_pposA_.p};
+        TokMeta tm{fg.seqA.p, fg.slotA.p, fg.posA.p};
         Transformer::Input in; in.x = d_pin_.p; in.x_stride = dP_;
         predictor_->set_same_seq_tokens(true);
         predictor_->forward(st_, in, 2 * B, tm, kvp, nullptr);
@@ -142,21 +175,24 @@ void Engine::record_frame(int B) {
     }
     predictor_->set_same_seq_tokens(false);
     for (int q = 1; q < 15; q++) { // :602-610 decode project(E_q[code_q]) at pos q+1
-        TokMeta tm{d_pseq_.p, d_pslot_.p + (size_t)(q + 1) * B, d_ppos_.p + (size_t)(q + 1) * B * 4};
+        TokMeta tm{d_pseq_.p, d_pslot_.p + (size_t)(q + 1) * B_, d_ppos_.p + (size_t)(q + 1) * B_ * 4};
         Transformer::Input in; in.x = d_proj_tab_[q].p; in.x_stride = dP_; in.idx_keys = d_keys_.p + q; in.idx_stride = 16;
         predictor_->forward(st_, in, B, tm, kvp, nullptr);
         ArgmaxEpi am{d_keys_.p + q + 1, 16, nullptr, 0};
         predictor_->head(st_, 0, B, q * Q3_CODEBOOK_SIZE, Q3_CODEBOOK_SIZE, nullptr, 0, &am);
     }
-    // :622-631 feedback ; :633-639 talker step at pos = cur_pos ; :550-555 next frame's code_0 (greedy branch)
+    // :622-631 feedback ; :633-639 talker step at pos = cur_pos ; :550-555 next frame's code_0
     launch_feedback_keys(st_, d_tab_ptrs_.p, d_tab_rows_.p, d_keys_.p, 16, d_tts_pad_.p, d_fb_.p, B);
     {
         TokMeta tm{d_tseq_.p, d_tslot_.p, d_tpos_.p};
         Transformer::Input in; in.x = d_fb_.p; in.x_stride = Q3_EMBD;
         talker_->set_same_seq_tokens(false);
         talker_->forward(st_, in, B, tm, kvt, nullptr);
-        if (code0_given_) talker_->head(st_, 0, B, 0, tl_stride_, d_tlogits_.p, tl_stride_, nullptr, -1, d_thidden_.p);
-        else {
+        if (sampled) { // llama/mod.rs:666-776 on device; greedy slots of a mixed batch take the kernel's T<=0 branch
+            talker_->head(st_, 0, B, 0, tl_stride_, d_tlogits_.p, tl_stride_, nullptr, -1, d_thidden_.p);
+            SampleArgs sa{d_tlogits_.p, tl_stride_, Q3_SAMPLE_END, d_temp_.p, d_topk_.p, d_topp_.p, d_maskeos_.p, d_rngkey_.p, d_draws_.p, d_next_key0_.p, 1};
+            launch_sample(st_, sa, B);
+        } else {
             ArgmaxEpi am{d_next_key0_.p, 1, d_maskeos_.p, 0};
             talker_->head(st_, 0, B, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p);
         }
@@ -165,239 +201,463 @@ void Engine::record_frame(int B) {
     launch_advance_keys(st_, a);
 }
 
-void Engine::build_graph(int B) {
-    if (graph_exec_ && graph_B_ == B && graph_given_ == code0_given_) return;
-    if (graph_exec_) { (void)hipGraphExecDestroy(graph_exec_); graph_exec_ = nullptr; }
-    if (graph_) { (void)hipGraphDestroy(graph_); graph_ = nullptr; }
-    Q3_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-    record_frame(B);
-    Q3_HIP(hipStreamEndCapture(st_, &graph_));
-    Q3_HIP(hipGraphInstantiate(&graph_exec_, graph_, nullptr, nullptr, 0));
-    graph_B_ = B; graph_given_ = code0_given_;
+Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {
+    std::unique_ptr<FrameGraph>& slot = graphs_[width * 2 + (sampled ? 1 : 0)];
+    if (!slot) {
+        slot.reset(new FrameGraph());
+        FrameGraph& fg = *slot;
+        fg.width = width;
+        const int B = width; // pass A = positions 0 and 1 of every slot: 2B tokens, slot b's pair stays in its own sequence
+        std::vector<int32_t> seqA(2 * B), slotA(2 * B), posA((size_t)2 * B * 4);
+        for (int b = 0; b < B; b++) {
+            seqA[b] = b; seqA[B + b] = b; slotA[b] = 0; slotA[B + b] = 1;
+            for (int s = 0; s < 4; s++) { posA[(size_t)b * 4 + s] = 0; posA[((size_t)B + b) * 4 + s] = 1; }
+        }
+        fg.seqA.alloc(2 * B); fg.seqA.upload(seqA.data(), 2 * B);
+        fg.slotA.alloc(2 * B); fg.slotA.upload(slotA.data(), 2 * B);
+        fg.posA.alloc(posA.size()); fg.posA.upload(posA.data(), posA.size());
+    }
+    FrameGraph& fg = *slot;
+    if (capture && !fg.exec) {
+        Q3_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
+        record_frame(fg, sampled);
+        Q3_HIP(hipStreamEndCapture(st_, &fg.graph));
+        Q3_HIP(hipGraphInstantiate(&fg.exec, fg.graph, nullptr, nullptr, 0));
+    }
+    return fg;
+}
+
+void Engine::upload_slot_state() {
+    const int W = B_;
+    std::vector<int32_t> tslot(W, 0), tpos((size_t)4 * W, 0);
+    for (int b = 0; b < W; b++) {
+        if (!slot_req_.empty() && slot_req_[b]) { const int t = h_nprompt_[b] + h_nfr_[b]; tslot[b] = t; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = t; }
+    }
+    d_maxframes_.upload(h_maxf_.data(), W); d_finished_.upload(h_fin_.data(), W); d_nframes_.upload(h_nfr_.data(), W);
+    d_tslot_.upload(tslot.data(), W); d_tpos_.upload(tpos.data(), (size_t)4 * W); d_maskeos_.upload(h_mask_.data(), W);
+    d_temp_.upload(h_temp_.data(), W); d_topk_.upload(h_topk_.data(), W); d_topp_.upload(h_topp_.data(), W);
+    slot_dirty_ = false;
+}
+
+// Prefill (engine.rs:455-462) of newly admitted sequences: all prompts as ONE token stream, chunked by the talker's launch
+// width; tokens of different sequences share a launch (per-token seq/slot/pos routing); each sequence's last token gets the
+// head: code_0 of its first frame (:550-555) + the hidden row the predictor starts from (:565-566).
+void Engine::prefill(const std::vector<Req*>& batch, bool sampled) {
+    size_t total = 0;
+    for (Req* r : batch) total += (size_t)r->r.n_prompt;
+    const int chunk = talker_->max_tok();
+    std::vector<float> stage((size_t)chunk * Q3_EMBD);
+    std::vector<int32_t> seq(chunk), slot(chunk), pos((size_t)4 * chunk);
+    size_t bi = 0; int t = 0; // cursor over (request, token)
+    size_t done = 0;
+    talker_->set_same_seq_tokens(true);
+    while (done < total) {
+        int n = 0;
+        std::vector<std::pair<Req*, int>> lasts; // (request, index inside this chunk) of final prompt tokens
+        while (n < chunk && bi < batch.size()) {
+            Req* r = batch[bi];
+            std::copy(r->r.prompt + (size_t)t * Q3_EMBD, r->r.prompt + (size_t)(t + 1) * Q3_EMBD, stage.begin() + (size_t)n * Q3_EMBD);
+            seq[n] = r->slot; slot[n] = t; pos[4 * n] = pos[4 * n + 1] = pos[4 * n + 2] = t; pos[4 * n + 3] = 0; // :306-314
+            if (t == r->r.n_prompt - 1) { lasts.emplace_back(r, n); bi++; t = 0; } else t++;
+            n++;
+        }
+        Q3_HIP(hipMemcpyAsync(d_prompt_.p, stage.data(), (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipMemcpyAsync(d_pf_seq_.p, seq.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipMemcpyAsync(d_pf_slot_.p, slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipMemcpyAsync(d_pf_pos_.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, st_));
+        Q3_HIP(hipStreamSynchronize(st_)); // staging vectors are reused by the next chunk
+        TokMeta tm{d_pf_seq_.p, d_pf_slot_.p, d_pf_pos_.p};
+        Transformer::Input in; in.x = d_prompt_.p; in.x_stride = Q3_EMBD;
+        talker_->forward(st_, in, n, tm, kv_t_->view(), nullptr);
+        for (auto& lb : lasts) {
+            const int sb = lb.first->slot, ti = lb.second;
+            if (sampled) {
+                talker_->head(st_, ti, 1, 0, tl_stride_, d_tlogits_.p + (size_t)sb * tl_stride_, tl_stride_, nullptr, -1, d_thidden_.p + (size_t)sb * Q3_EMBD);
+                SampleArgs sa{d_tlogits_.p + (size_t)sb * tl_stride_, tl_stride_, Q3_SAMPLE_END, d_temp_.p + sb, d_topk_.p + sb, d_topp_.p + sb,
+                              d_maskeos_.p + sb, d_rngkey_.p + (size_t)sb * 8, d_draws_.p + sb, d_keys_.p + (size_t)sb * 16, 16};
+                launch_sample(st_, sa, 1);
+            } else {
+                ArgmaxEpi am{d_keys_.p + (size_t)sb * 16, 16, d_maskeos_.p + sb, 0};
+                talker_->head(st_, ti, 1, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p + (size_t)sb * Q3_EMBD);
+            }
+        }
+        done += (size_t)n;
+    }
+}
+
+// ---------------- decoder thread (the reference decodes on a second thread too, engine.rs:495-543): it owns every codec
+// launch, so the ~200 kernel launches of a chunk never delay the AR stream's launches ----------------
+void Engine::decoder_main() {
+    try {
+        Q3_HIP(hipSetDevice(dev_)); // HIP's current device is per thread
+        const int spf = codec_->samples_per_frame();
+        for (;;) {
+            DecTask t;
+            {
+                std::unique_lock<std::mutex> lk(dmu_);
+                dcv_.wait(lk, [&] { return dec_stop_ || !dq_.empty(); });
+                if (dq_.empty()) return;
+                t = std::move(dq_.front());
+                dq_.pop_front();
+            }
+            Req* r = t.r;
+            const int lane = r->cs % (int)st2_.size();
+            if (!t.fence) {
+                const int nf = (int)t.codes.size() / 16;
+                Q3_CHECK(r->pcm_enq + (size_t)nf * spf <= slot_cap_, "pcm staging overflow");
+                // engine.rs:520: decode the chunk -- enqueued on a codec stream, overlapping the next AR frames
+                const int got = codec_->decode_async(st2_[lane], r->cs, t.codes.data(), nf, t.is_final, pcm_pinned_ + (size_t)r->cs * slot_cap_ + r->pcm_enq, lane);
+                r->pcm_enq += (size_t)std::max(got, 0);
+            }
+            hipEvent_t ev;
+            Q3_HIP(hipEventCreate(&ev));
+            Q3_HIP(hipEventRecord(ev, st2_[lane])); // first one = the reference's first stream_tx.send (:522-523)
+            {
+                std::lock_guard<std::mutex> lk(dmu_);
+                comp_.push_back(Completion{r, ev, r->pcm_enq, t.fence});
+                if (!t.fence) stats.codec_calls++;
+            }
+            dcv_.notify_all();
+        }
+    } catch (const std::exception& ex) {
+        std::lock_guard<std::mutex> lk(dmu_);
+        derr_ = ex.what();
+        dcv_.notify_all();
+    }
+}
+
+// collects finished codec work: PCM watermark per request, first-chunk latency, request completion
+void Engine::harvest(bool block) {
+    for (;;) {
+        Completion c;
+        {
+            std::unique_lock<std::mutex> lk(dmu_);
+            if (!derr_.empty()) throw Error("decoder thread: " + derr_);
+            if (comp_.empty()) {
+                if (!block) return;
+                dcv_.wait_for(lk, std::chrono::milliseconds(2));
+                if (comp_.empty()) return;
+            }
+            c = comp_.front();
+            if (!block && hipEventQuery(c.ev) != hipSuccess) return; // completions of a lane finish in order; keep it simple: FIFO
+            comp_.pop_front();
+        }
+        Q3_HIP(hipEventSynchronize(c.ev));
+        Req* r = c.r;
+        std::lock_guard<std::mutex> lk(mu_);
+        r->pcm_ready = c.pcm_after;
+        if (!r->first_seen && c.pcm_after > 0) {
+            float ms = 0;
+            Q3_HIP(hipEventElapsedTime(&ms, r->ev_admit, c.ev));
+            r->first_chunk_ms = (r->t_admit - r->t_submit) + ms;
+            r->first_seen = true;
+        }
+        (void)hipEventDestroy(c.ev);
+        if (c.fence) {
+            r->pcm.assign(pcm_pinned_ + (size_t)r->cs * slot_cap_, pcm_pinned_ + (size_t)r->cs * slot_cap_ + c.pcm_after);
+            cs_free_.push_back(r->cs);
+            r->cs = -1;
+            r->state = REQ_DONE; r->t_done = now_ms();
+            n_draining_--;
+            cv_.notify_all();
+        }
+        block = false; // after one blocking wait, drain whatever else is ready
+    }
+}
+
+int64_t Engine::submit(const GenRequest& g, bool want_pcm, bool copy_prompt) {
+    Q3_CHECK(g.prompt && g.n_prompt >= 1 && g.n_prompt <= p_.max_prompt, "prompt length out of range");
+    Q3_CHECK(g.max_steps >= 0 && g.max_steps <= p_.max_steps, "max_steps out of range");
+    std::unique_ptr<Req> r(new Req());
+    r->r = g;
+    if (copy_prompt) { r->prompt_own.assign(g.prompt, g.prompt + (size_t)g.n_prompt * Q3_EMBD); r->r.prompt = r->prompt_own.data(); }
+    r->want_pcm = want_pcm && codec_;
+    r->t_submit = now_ms();
+    r->seed = g.sampler.has_seed ? g.sampler.seed
+                                 : (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(std::chrono::system_clock::now().time_since_epoch()).count(); // :473-478
+    std::lock_guard<std::mutex> lk(mu_);
+    r->id = next_id_++;
+    Req* raw = r.get();
+    reqs_[raw->id] = std::move(r);
+    pending_.push_back(raw);
+    cv_.notify_all();
+    return raw->id;
+}
+
+// moves queued requests into free slots (lowest slot first, so the active slots stay packed and a narrow graph suffices)
+void Engine::admit() {
+    std::vector<Req*> batch;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        while (!pending_.empty() && n_active_ < B_) {
+            Req* r = pending_.front();
+            if (r->want_pcm && cs_free_.empty()) break; // every codec stream still drains: admit after the next harvest
+            int slot = -1;
+            for (int b = 0; b < B_; b++) if (!slot_req_[b]) { slot = b; break; }
+            if (slot < 0) break;
+            pending_.pop_front();
+            r->slot = slot;
+            if (r->want_pcm) { r->cs = cs_free_.back(); cs_free_.pop_back(); }
+            r->state = REQ_RUNNING; r->t_admit = now_ms();
+            slot_req_[slot] = r; n_active_++;
+            batch.push_back(r);
+        }
+    }
+    if (batch.empty()) return;
+    bool sampled = false;
+    for (int b = 0; b < B_; b++) if (slot_req_[b] && slot_req_[b]->r.sampler.temperature > 0.0f) sampled = true;
+    const q3_u64 armed[17] = {pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0)};
+    const uint32_t zero = 0;
+    for (Req* r : batch) {
+        const int b = r->slot;
+        kv_t_->release(b);
+        kv_t_->ensure(b, r->r.n_prompt + r->r.max_steps + 1);
+        h_maxf_[b] = r->r.max_steps; h_fin_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = r->r.n_prompt;
+        h_mask_[b] = r->r.mask_eos ? Q3_CODEC_EOS : -1;
+        h_temp_[b] = r->r.sampler.temperature; h_topk_[b] = r->r.sampler.top_k; h_topp_[b] = r->r.sampler.top_p;
+        StdRng rng(r->seed); // llama/mod.rs:648: the device regenerates this ChaCha12 stream from the key and a draw counter
+        Q3_HIP(hipMemcpy(d_rngkey_.p + (size_t)b * 8, rng.key(), 32, hipMemcpyHostToDevice));
+        Q3_HIP(hipMemcpy(d_draws_.p + b, &zero, 4, hipMemcpyHostToDevice));
+        Q3_HIP(hipMemcpy(d_keys_.p + (size_t)b * 16, armed, 16 * 8, hipMemcpyHostToDevice));
+        Q3_HIP(hipMemcpy(d_next_key0_.p + b, armed, 8, hipMemcpyHostToDevice));
+        if (r->want_pcm) codec_->reset(r->cs);
+        r->chunker.reset(new Chunker([this, r](const int64_t* codes, int n_codes, bool is_final) {
+            if (!r->want_pcm) return;
+            { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, std::vector<int64_t>(codes, codes + n_codes), is_final, false}); }
+            dcv_.notify_all();
+        }));
+        Q3_HIP(hipEventCreate(&r->ev_admit));
+    }
+    upload_slot_state();
+    hipEvent_t e0, e1;
+    Q3_HIP(hipEventCreate(&e0)); Q3_HIP(hipEventCreate(&e1));
+    Q3_HIP(hipEventRecord(e0, st_));
+    for (Req* r : batch) Q3_HIP(hipEventRecord(r->ev_admit, st_)); // the AR stream is idle here: marks "admitted"
+    prefill(batch, sampled);
+    Q3_HIP(hipEventRecord(e1, st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, e0, e1)); stats.prefill_ms += ms; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    const double t = now_ms();
+    std::lock_guard<std::mutex> lk(mu_);
+    for (Req* r : batch) r->prefill_ms = t - r->t_submit;
+}
+
+void Engine::finish_ar(Req* r) { // engine.rs:644-649: final flush of the chunker, then the decoder drains
+    r->chunker->push(nullptr, 0, true);
+    const int b = r->slot;
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        slot_req_[b] = nullptr; n_active_--;
+        r->slot = -1;
+        if (r->want_pcm) { r->state = REQ_DRAINING; n_draining_++; }
+        else { r->state = REQ_DONE; r->t_done = now_ms(); cv_.notify_all(); }
+    }
+    if (r->want_pcm) {
+        { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, {}, false, true}); }
+        dcv_.notify_all();
+    }
+    h_fin_[b] = 1; h_maxf_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = 0; h_temp_[b] = 0.0f; h_mask_[b] = -1;
+    kv_t_->release(b);
+    kv_t_->ensure(b, 1); // idle slots keep stepping inside the graph; they write to their one reserved page
+    slot_dirty_ = true;
+}
+
+static int pick_width(int hi, int W) { // graph widths: powers of two (and the full width)
+    int w = 1;
+    while (w < hi) w <<= 1;
+    return std::min(w, W);
+}
+
+// one streaming step (4 frames, engine.rs:505-512) for every active slot
+void Engine::run_group() {
+    int hi = 0, remaining = 0;
+    bool sampled = false;
+    for (int b = 0; b < B_; b++)
+        if (Req* r = slot_req_[b]) {
+            hi = b + 1;
+            remaining = std::max(remaining, r->r.max_steps - h_nfr_[b]);
+            if (r->r.sampler.temperature > 0.0f) sampled = true;
+        }
+    if (slot_dirty_) upload_slot_state();
+    const int width = pick_width(hi, B_);
+    const int group = std::max(1, std::min(4, remaining));
+    const bool eager = instrument_ || !p_.use_graph;
+    FrameGraph& fg = frame_graph(width, sampled, !eager);
+    if (instrument_) { talker_->timer = &timer_; predictor_->timer = &timer_; talker_->timer_gu = &timer_gu_; }
+    hipEvent_t e0, e1;
+    Q3_HIP(hipEventCreate(&e0)); Q3_HIP(hipEventCreate(&e1));
+    Q3_HIP(hipEventRecord(e0, st_));
+    for (int g = 0; g < group; g++) {
+        if (eager) record_frame(fg, sampled);
+        else Q3_HIP(hipGraphLaunch(fg.exec, st_));
+    }
+    Q3_HIP(hipEventRecord(e1, st_));
+    Q3_HIP(hipStreamSynchronize(st_));
+    { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, e0, e1)); stats.frame_loop_ms += ms; }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    stats.steps++; stats.slot_frames += (double)width * group;
+    talker_->timer = nullptr; predictor_->timer = nullptr; talker_->timer_gu = nullptr;
+    if (instrument_) {
+        stats.gemv_ms += timer_.collect_ms(); stats.gemv_bytes += timer_.bytes; stats.gemv_launches += timer_.launches; timer_.bytes = 0; timer_.launches = 0;
+        stats.gu_ms += timer_gu_.collect_ms(); stats.gu_bytes += timer_gu_.bytes; stats.gu_launches += timer_gu_.launches; timer_gu_.bytes = 0; timer_gu_.launches = 0;
+    }
+    d_nframes_.download(h_nfr_.data(), width); d_finished_.download(h_fin_.data(), width);
+    std::vector<int32_t> hbuf;
+    for (int b = 0; b < width; b++) {
+        Req* r = slot_req_[b];
+        if (!r) continue;
+        if (h_nfr_[b] > r->fed) { // hand new frames to the chunker (engine.rs:613-620)
+            const int nnew = h_nfr_[b] - r->fed;
+            hbuf.resize((size_t)nnew * 16);
+            Q3_HIP(hipMemcpy(hbuf.data(), d_hist_.p + (size_t)b * hist_stride_ + (size_t)r->fed * 16, (size_t)nnew * 64, hipMemcpyDeviceToHost));
+            { std::lock_guard<std::mutex> lk(mu_); r->codes.insert(r->codes.end(), hbuf.begin(), hbuf.end()); r->fed = h_nfr_[b]; }
+            for (int f = 0; f < nnew; f++) {
+                int64_t fc[16];
+                for (int q = 0; q < 16; q++) fc[q] = hbuf[(size_t)f * 16 + q];
+                r->chunker->push(fc, 16, false);
+            }
+            stats.frames += nnew;
+        }
+        if (h_fin_[b] || h_nfr_[b] >= r->r.max_steps) finish_ar(r);
+    }
+}
+
+bool Engine::step() {
+    if (codec_ && !dec_started_) { dec_started_ = true; dec_thread_ = std::thread([this] { decoder_main(); }); }
+    harvest(false);
+    admit();
+    if (n_active_ > 0) run_group();
+    else if (n_draining_ > 0) harvest(true);
+    std::lock_guard<std::mutex> lk(mu_);
+    return n_active_ > 0 || n_draining_ > 0 || !pending_.empty();
+}
+
+ReqStatus Engine::poll(int64_t id) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = reqs_.find(id);
+    Q3_CHECK(it != reqs_.end(), "unknown request id");
+    const Req& r = *it->second;
+    ReqStatus s;
+    s.state = r.state; s.n_frames = r.fed; s.n_pcm = (int64_t)(r.state == REQ_DONE ? r.pcm.size() : r.pcm_ready);
+    s.queue_ms = r.t_admit > 0 ? r.t_admit - r.t_submit : now_ms() - r.t_submit;
+    s.prefill_ms = r.prefill_ms; s.first_chunk_ms = r.first_chunk_ms;
+    s.total_ms = (r.state == REQ_DONE ? r.t_done : now_ms()) - r.t_submit;
+    return s;
+}
+
+void Engine::fetch(int64_t id, int32_t* codes, int frame_off, int max_frames, float* pcm, int64_t pcm_off, int64_t pcm_cap, int* got_frames, int64_t* got_pcm) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = reqs_.find(id);
+    Q3_CHECK(it != reqs_.end(), "unknown request id");
+    const Req& r = *it->second;
+    int nf = 0; int64_t np = 0;
+    if (codes && frame_off >= 0 && frame_off < r.fed) {
+        nf = std::min(max_frames, r.fed - frame_off);
+        std::copy(r.codes.begin() + (size_t)frame_off * 16, r.codes.begin() + (size_t)(frame_off + nf) * 16, codes);
+    }
+    if (pcm && pcm_off >= 0) {
+        const bool done = r.state == REQ_DONE;
+        const int64_t avail = (int64_t)(done ? r.pcm.size() : r.pcm_ready);
+        const float* src = done ? r.pcm.data() : (r.cs >= 0 ? pcm_pinned_ + (size_t)r.cs * slot_cap_ : nullptr);
+        if (src && pcm_off < avail) { np = std::min(pcm_cap, avail - pcm_off); std::copy(src + pcm_off, src + pcm_off + np, pcm); }
+    }
+    if (got_frames) *got_frames = nf;
+    if (got_pcm) *got_pcm = np;
+}
+
+bool Engine::wait(int64_t id, double timeout_ms) {
+    const double t0 = now_ms();
+    for (;;) {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            auto it = reqs_.find(id);
+            Q3_CHECK(it != reqs_.end(), "unknown request id");
+            if (it->second->state == REQ_DONE || it->second->state == REQ_FAILED) return true;
+            if (timeout_ms >= 0 && now_ms() - t0 > timeout_ms) return false;
+            if (driver_on_) { cv_.wait_for(lk, std::chrono::milliseconds(5)); continue; }
+        }
+        step();
+    }
+}
+
+void Engine::release(int64_t id) {
+    std::lock_guard<std::mutex> lk(mu_);
+    auto it = reqs_.find(id);
+    Q3_CHECK(it != reqs_.end(), "unknown request id");
+    Q3_CHECK(it->second->state == REQ_DONE || it->second->state == REQ_FAILED, "request still in flight");
+    if (it->second->ev_admit) (void)hipEventDestroy(it->second->ev_admit);
+    reqs_.erase(it);
+}
+
+void Engine::start_driver() {
+    std::lock_guard<std::mutex> lk(mu_);
+    if (driver_on_) return;
+    driver_on_ = true; driver_stop_ = false;
+    driver_ = std::thread([this] {
+        try {
+            Q3_HIP(hipSetDevice(dev_));
+            for (;;) {
+                const bool busy = step();
+                std::unique_lock<std::mutex> lk(mu_);
+                if (driver_stop_) return;
+                if (!busy) cv_.wait_for(lk, std::chrono::milliseconds(1), [this] { return driver_stop_ || !pending_.empty(); });
+            }
+        } catch (const std::exception& ex) {
+            std::lock_guard<std::mutex> lk(mu_);
+            for (auto& kv : reqs_) if (kv.second->state != REQ_DONE) { kv.second->state = REQ_FAILED; kv.second->error = ex.what(); }
+            cv_.notify_all();
+        }
+    });
+}
+void Engine::stop_driver() {
+    {
+        std::lock_guard<std::mutex> lk(mu_);
+        if (!driver_on_) return;
+        driver_stop_ = true;
+        cv_.notify_all();
+    }
+    driver_.join();
+    std::lock_guard<std::mutex> lk(mu_);
+    driver_on_ = false;
+}
+
+int Engine::register_voice(const Voice& v) {
+    Q3_CHECK(v.spk_emb.size() == (size_t)Q3_EMBD, "speaker embedding must have 2048 values");
+    std::lock_guard<std::mutex> lk(mu_);
+    voices_.push_back(v);
+    return (int)voices_.size() - 1;
+}
+const Voice& Engine::voice(int id) const {
+    Q3_CHECK(id >= 0 && id < (int)voices_.size(), "unknown voice id");
+    return voices_[id];
 }
 
 void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<GenResult>& out, bool want_pcm) {
-    const int B = (int)reqs.size();
-    Q3_CHECK(B >= 1 && B <= B_, "batch size exceeds max_batch");
-    out.assign(B, GenResult());
-    const double t0 = now_ms();
-    // the graph is captured for the engine's full batch width; unused slots idle as finished sequences
-    const int W = B_;
-    bool any_sampled = false;
-    int max_steps_all = 0;
-    std::vector<int32_t> maxf(W, 0), mask(W, -1), fin(W, 1), nfr(W, 0), tslot(W, 0), tpos((size_t)4 * W, 0);
-    hipEvent_t ev0, ev1;
-    Q3_HIP(hipEventCreate(&ev0)); Q3_HIP(hipEventCreate(&ev1));
-    Q3_HIP(hipEventRecord(ev0, st_));
-    bool any_sampled_req = false;
-    for (int b = 0; b < B; b++) { mask[b] = reqs[b].mask_eos ? Q3_CODEC_EOS : -1; if (reqs[b].sampler.temperature > 0.0f) any_sampled_req = true; }
-    d_maskeos_.upload(mask.data(), W);
-    {
-        std::vector<q3_u64> k0((size_t)16 * W, pack_key(-INFINITY, 0)), n0(W, pack_key(-INFINITY, 0));
-        d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
+    const int n = (int)reqs.size();
+    Q3_CHECK(n >= 1, "no requests");
+    Q3_CHECK(!driver_on_, "generate_batch cannot be mixed with a running scheduler thread");
+    out.assign(n, GenResult());
+    std::vector<int64_t> ids(n);
+    for (int i = 0; i < n; i++) ids[i] = submit(reqs[i], want_pcm, false);
+    double t_ar_end = 0;
+    while (step()) {
+        if (t_ar_end == 0 && n_active_ == 0) { std::lock_guard<std::mutex> lk(mu_); if (pending_.empty()) t_ar_end = now_ms(); }
     }
-    // ---------------- prefill (engine.rs:455-462): all prompts as ONE token stream, chunked by the talker's launch width ----------------
-    // tokens of different sequences share a launch (per-token seq/slot/pos routing); each sequence's last token gets the head.
-    {
-        size_t total = 0;
-        for (int b = 0; b < B; b++) {
-            const GenRequest& r = reqs[b];
-            Q3_CHECK(r.n_prompt >= 1 && r.n_prompt <= p_.max_prompt, "prompt length out of range");
-            Q3_CHECK(r.max_steps >= 0 && r.max_steps <= p_.max_steps, "max_steps out of range");
-            kv_t_->release(b);
-            kv_t_->ensure(b, r.n_prompt + r.max_steps + 1);
-            total += (size_t)r.n_prompt;
-            maxf[b] = r.max_steps; fin[b] = 0;
-            tslot[b] = r.n_prompt; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = r.n_prompt;
-            max_steps_all = std::max(max_steps_all, r.max_steps);
-            if (r.sampler.temperature > 0.0f) any_sampled = true;
+    if (t_ar_end > 0) stats.codec_ms += now_ms() - t_ar_end; // only the part of the codec work the AR loop did not hide
+    for (int i = 0; i < n; i++) {
+        {
+            std::lock_guard<std::mutex> lk(mu_);
+            Req& r = *reqs_.at(ids[i]);
+            Q3_CHECK(r.state == REQ_DONE, "request did not finish");
+            out[i].codes = std::move(r.codes); out[i].n_frames = r.fed; out[i].pcm = std::move(r.pcm);
+            out[i].prefill_ms = r.prefill_ms; out[i].first_chunk_ms = r.first_chunk_ms; out[i].total_ms = r.t_done - r.t_submit;
         }
-        const int chunk = talker_->max_tok();
-        if (d_prompt_.n < (size_t)chunk * Q3_EMBD) d_prompt_.alloc((size_t)chunk * Q3_EMBD);
-        std::vector<float> stage((size_t)chunk * Q3_EMBD);
-        std::vector<int32_t> seq(chunk), slot(chunk), pos((size_t)4 * chunk);
-        int b = 0, t = 0; // cursor over (sequence, token)
-        size_t done = 0;
-        talker_->set_same_seq_tokens(true);
-        while (done < total) {
-            int n = 0;
-            std::vector<std::pair<int, int>> lasts; // (sequence, index inside this chunk) of final prompt tokens
-            while (n < chunk && b < B) {
-                const GenRequest& r = reqs[b];
-                std::copy(r.prompt + (size_t)t * Q3_EMBD, r.prompt + (size_t)(t + 1) * Q3_EMBD, stage.begin() + (size_t)n * Q3_EMBD);
-                seq[n] = b; slot[n] = t; pos[4 * n] = pos[4 * n + 1] = pos[4 * n + 2] = t; pos[4 * n + 3] = 0; // :306-314
-                if (t == r.n_prompt - 1) { lasts.emplace_back(b, n); b++; t = 0; } else t++;
-                n++;
-            }
-            Q3_HIP(hipMemcpyAsync(d_prompt_.p, stage.data(), (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipMemcpyAsync(d_pf_seq_.p, seq.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipMemcpyAsync(d_pf_slot_.p, slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipMemcpyAsync(d_pf_pos_.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, st_));
-            Q3_HIP(hipStreamSynchronize(st_)); // staging vectors are reused by the next chunk
-            TokMeta tm{d_pf_seq_.p, d_pf_slot_.p, d_pf_pos_.p};
-            Transformer::Input in; in.x = d_prompt_.p; in.x_stride = Q3_EMBD;
-            talker_->forward(st_, in, n, tm, kv_t_->view(), nullptr);
-            for (auto& lb : lasts) { // logits / code_0 + hidden of the LAST prompt token (engine.rs:550-554,565-566)
-                const int sb = lb.first, ti = lb.second;
-                if (any_sampled_req)
-                    talker_->head(st_, ti, 1, 0, tl_stride_, d_tlogits_.p + (size_t)sb * tl_stride_, tl_stride_, nullptr, -1, d_thidden_.p + (size_t)sb * Q3_EMBD);
-                else {
-                    ArgmaxEpi am{d_keys_.p + (size_t)sb * 16, 16, d_maskeos_.p + sb, 0};
-                    talker_->head(st_, ti, 1, 0, tl_stride_, nullptr, 0, &am, Q3_SAMPLE_END, d_thidden_.p + (size_t)sb * Q3_EMBD);
-                }
-            }
-            done += (size_t)n;
-        }
+        release(ids[i]);
     }
-    for (int b = B; b < W; b++) { tslot[b] = 0; } // idle slots write to their single reserved page
-    d_maxframes_.upload(maxf.data(), W); d_finished_.upload(fin.data(), W);
-    d_nframes_.upload(nfr.data(), W); d_tslot_.upload(tslot.data(), W); d_tpos_.upload(tpos.data(), (size_t)4 * W);
-    Q3_HIP(hipEventRecord(ev1, st_));
-    Q3_HIP(hipStreamSynchronize(st_));
-    { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, ev0, ev1)); stats.prefill_ms += ms; }
-    const double t_prefill = now_ms();
-    for (int b = 0; b < B; b++) out[b].prefill_ms = t_prefill - t0;
-
-    // ---------------- host-side per-sequence helpers ----------------
-    std::vector<Sampler> samplers;
-    for (int b = 0; b < B; b++) {
-        const SamplerConfig& sc = reqs[b].sampler;
-        const uint64_t seed = sc.has_seed ? sc.seed : (uint64_t)std::chrono::duration_cast<std::chrono::nanoseconds>(
-                                                           std::chrono::system_clock::now().time_since_epoch()).count(); // :473-478
-        samplers.emplace_back(sc.temperature, sc.top_k, sc.top_p, seed);
-    }
-    const int spf = codec_ ? codec_->samples_per_frame() : 0;
-    std::vector<std::unique_ptr<Chunker>> chunkers;
-    std::vector<size_t> pcm_len(B, 0);        // samples enqueued so far per sequence (pinned staging area, slot b)
-    std::vector<hipEvent_t> ev_first(B, nullptr);
-    const size_t slot_cap = codec_ ? (size_t)p_.max_steps * spf : 0;
-    // decoder thread (the reference decodes on a second thread too, engine.rs:495-543): it owns every codec launch, so
-    // the ~200 kernel launches of a chunk never delay the AR stream's launches on this thread
-    struct DecTask { int b; std::vector<int64_t> codes; bool is_final; };
-    std::deque<DecTask> dq;
-    std::mutex dmu;
-    std::condition_variable dcv;
-    bool ddone = false;
-    std::string derr;
-    std::thread dec_thread;
-    const bool use_codec = codec_ && want_pcm;
-    if (use_codec) {
-        for (int b = 0; b < B; b++) codec_->reset(b);
-        dec_thread = std::thread([&]() {
-            try {
-                Q3_HIP(hipSetDevice(dev_)); // HIP's current device is per thread
-                for (;;) {
-                    DecTask t;
-                    {
-                        std::unique_lock<std::mutex> lk(dmu);
-                        dcv.wait(lk, [&] { return ddone || !dq.empty(); });
-                        if (dq.empty()) return;
-                        t = std::move(dq.front());
-                        dq.pop_front();
-                    }
-                    const int b = t.b, nf = (int)t.codes.size() / 16;
-                    Q3_CHECK(pcm_len[b] + (size_t)nf * spf <= slot_cap, "pcm staging overflow");
-                    const int lane = b % (int)st2_.size();
-                    // engine.rs:520: decode the chunk -- enqueued on a codec stream, overlapping the next AR frames
-                    const int got = codec_->decode_async(st2_[lane], b, t.codes.data(), nf, t.is_final, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b], lane);
-                    pcm_len[b] += (size_t)std::max(got, 0);
-                    stats.codec_calls++;
-                    if (!ev_first[b]) { Q3_HIP(hipEventCreate(&ev_first[b])); Q3_HIP(hipEventRecord(ev_first[b], st2_[lane])); } // first stream_tx.send, :522-523
-                }
-            } catch (const std::exception& ex) { std::lock_guard<std::mutex> lk(dmu); derr = ex.what(); }
-        });
-    }
-    for (int b = 0; b < B; b++) {
-        chunkers.emplace_back(new Chunker([&, b](const int64_t* codes, int n_codes, bool is_final) {
-            if (!use_codec) return;
-            { std::lock_guard<std::mutex> lk(dmu); dq.push_back(DecTask{b, std::vector<int64_t>(codes, codes + n_codes), is_final}); }
-            dcv.notify_one();
-        }));
-    }
-    hipEvent_t ev_t0;
-    Q3_HIP(hipEventCreate(&ev_t0));
-    Q3_HIP(hipEventRecord(ev_t0, st_)); // the AR stream is idle here (prefill was synchronised): marks "prefill done"
-
-    // ---------------- frame loop ----------------
-    code0_given_ = any_sampled;
-    LaunchTimer timer, timer_gu;
-    const bool eager = instrument_ || !p_.use_graph;
-    if (instrument_) { talker_->timer = &timer; predictor_->timer = &timer; talker_->timer_gu = &timer_gu; }
-    if (!eager) build_graph(W);
-    std::vector<int32_t> fed(B, 0), hbuf;
-    std::vector<float> hlogits;
-    int step = 0;
-    bool all_done = (max_steps_all == 0);
-    while (!all_done && step < max_steps_all) {
-        const int group = any_sampled ? 1 : std::min(4, max_steps_all - step);
-        Q3_HIP(hipEventRecord(ev0, st_));
-        for (int g = 0; g < group; g++) {
-            if (any_sampled) { // host sampler on logits [0,2160) (llama/mod.rs:666-775; greedy requests take its T<=0 branch)
-                hlogits.resize((size_t)W * tl_stride_);
-                d_tlogits_.download(hlogits.data(), hlogits.size());
-                for (int b = 0; b < B; b++) {
-                    float* lg = hlogits.data() + (size_t)b * tl_stride_;
-                    if (reqs[b].mask_eos) lg[Q3_CODEC_EOS] = -INFINITY;
-                    const q3_u64 key = pack_key(0.0f, samplers[b].sample(lg, tl_stride_, 0, Q3_SAMPLE_END));
-                    Q3_HIP(hipMemcpy(d_keys_.p + (size_t)16 * b, &key, 8, hipMemcpyHostToDevice));
-                }
-            }
-            if (eager) record_frame(W);
-            else Q3_HIP(hipGraphLaunch(graph_exec_, st_));
-        }
-        Q3_HIP(hipEventRecord(ev1, st_));
-        Q3_HIP(hipStreamSynchronize(st_));
-        { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, ev0, ev1)); stats.frame_loop_ms += ms; }
-        if (instrument_) {
-            stats.gemv_ms += timer.collect_ms(); stats.gemv_bytes += timer.bytes; stats.gemv_launches += timer.launches; timer.bytes = 0; timer.launches = 0;
-            stats.gu_ms += timer_gu.collect_ms(); stats.gu_bytes += timer_gu.bytes; stats.gu_launches += timer_gu.launches; timer_gu.bytes = 0; timer_gu.launches = 0;
-        }
-        step += group;
-        d_nframes_.download(nfr.data(), W); d_finished_.download(fin.data(), W);
-        all_done = true;
-        for (int b = 0; b < B; b++) {
-            if (nfr[b] > fed[b]) { // hand new frames to the chunker (engine.rs:613-620)
-                const int nnew = nfr[b] - fed[b];
-                hbuf.resize((size_t)nnew * 16);
-                Q3_HIP(hipMemcpy(hbuf.data(), d_hist_.p + (size_t)b * hist_stride_ + (size_t)fed[b] * 16, (size_t)nnew * 64, hipMemcpyDeviceToHost));
-                out[b].codes.insert(out[b].codes.end(), hbuf.begin(), hbuf.end());
-                for (int f = 0; f < nnew; f++) {
-                    int64_t fc[16];
-                    for (int q = 0; q < 16; q++) fc[q] = hbuf[(size_t)f * 16 + q];
-                    chunkers[b]->push(fc, 16, false);
-                }
-                stats.frames += nnew;
-                fed[b] = nfr[b];
-            }
-            if (!fin[b] && nfr[b] < reqs[b].max_steps) all_done = false;
-        }
-    }
-    talker_->timer = nullptr; predictor_->timer = nullptr; talker_->timer_gu = nullptr;
-    for (int b = 0; b < B; b++) chunkers[b]->push(nullptr, 0, true); // :644
-    {
-        const double c0 = now_ms();
-        if (use_codec) {
-            { std::lock_guard<std::mutex> lk(dmu); ddone = true; }
-            dcv.notify_one();
-            dec_thread.join();                                   // engine.rs:647-649
-            if (!derr.empty()) throw Error("decoder thread: " + derr);
-        }
-        for (auto s2 : st2_) Q3_HIP(hipStreamSynchronize(s2));
-        stats.codec_ms += now_ms() - c0;     // only the part of the codec work the AR loop did not hide
-    }
-    for (int b = 0; b < B; b++) {
-        out[b].n_frames = fed[b];
-        if (want_pcm && codec_) out[b].pcm.assign(pcm_pinned_ + (size_t)b * slot_cap, pcm_pinned_ + (size_t)b * slot_cap + pcm_len[b]);
-        if (ev_first[b]) {
-            float ms = 0;
-            Q3_HIP(hipEventElapsedTime(&ms, ev_t0, ev_first[b]));
-            out[b].first_chunk_ms = out[b].prefill_ms + ms;
-            (void)hipEventDestroy(ev_first[b]);
-        }
-        out[b].total_ms = now_ms() - t0;
-    }
-    (void)hipEventDestroy(ev_t0);
-    (void)hipEventDestroy(ev0); (void)hipEventDestroy(ev1);
 }
 
 } // namespace q3

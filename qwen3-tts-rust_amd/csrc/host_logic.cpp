@@ -52,7 +52,7 @@ int32_t Sampler::sample(const float* logits, int n_vocab, int start, int end) {
     if (top_k_ > 0 && (size_t)top_k_ < c.size()) c.resize((size_t)top_k_);                                  // :711-713
     const float max_logit = c[0].second;
     float sum = 0.0f;
-    for (auto& e : c) { e.second = std::exp((e.second - max_logit) / temperature_); sum += e.second; }      // :716-726
+    for (auto& e : c) { e.second = q3_expf((e.second - max_logit) / temperature_); sum += e.second; }      // :716-726
     if (sum > 0.0f) for (auto& e : c) e.second /= sum;
     if (top_p_ < 1.0f) {                                                                                     // :734-753
         float cum = 0.0f; size_t cut = c.size();

@@ -19,6 +19,7 @@ class StdRng {
 public:
     explicit StdRng(uint64_t seed);
     uint32_t next_u32();
+    const uint32_t* key() const { return key_; } // the device sampler regenerates the same stream from the key + a draw count
 private:
     uint32_t key_[8]; uint64_t counter_ = 0; uint32_t buf_[16]; int idx_ = 16;
 };
@@ -29,6 +30,7 @@ public:
         : temperature_(temperature), top_k_(top_k), top_p_(top_p), rng_(seed) {}
     static Sampler greedy() { return Sampler(0.0f, 0, 1.0f, 42); } // :653-664
     int32_t sample(const float* logits, int n_vocab, int start, int end);
+    const StdRng& rng() const { return rng_; }
 private:
     float temperature_; int top_k_; float top_p_; StdRng rng_;
 };

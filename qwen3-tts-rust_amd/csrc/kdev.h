@@ -36,6 +36,7 @@ typedef unsigned long long u64;
 // picks the largest value and, among equal values, the SMALLEST index (first max, llama/mod.rs:690-701)
 __host__ __device__ __forceinline__ u64 pack_key(float v, int idx) {
     uint32_t b = q3_f32_bits(v);
+    if (b == 0x80000000u) b = 0u; // -0.0 compares equal to +0.0 in the reference's `>`
     uint32_t ord = (b & 0x80000000u) ? ~b : (b | 0x80000000u);
     return ((u64)ord << 32) | (uint32_t)(~(uint32_t)idx);
 }

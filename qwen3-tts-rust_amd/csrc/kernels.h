@@ -146,4 +146,14 @@ struct AdvanceKeysArgs {
 };
 void launch_advance_keys(hipStream_t st, const AdvanceKeysArgs& a);
 
+// on-device LlamaSampler::sample (sampler.hip): one workgroup per sequence over logits[b*stride + [0,n)), n <= 4096
+struct SampleArgs {
+    const float* logits; int stride; int n;
+    const float* temperature; const int32_t* top_k; const float* top_p; // per sequence (SamplerConfig, engine.rs:13-45)
+    const int32_t* mask_idx;                                            // optional per sequence: index forced to -inf
+    const uint32_t* rng_key; uint32_t* draws;                           // [B][8] ChaCha12 key, [B] u32 words consumed so far
+    q3_u64* out_key; int out_stride;                                    // receives pack_key(0, token)
+};
+void launch_sample(hipStream_t st, const SampleArgs& a, int B);
+
 } // namespace q3

@@ -38,7 +38,16 @@ class Stats(C.Structure):
     _fields_ = [("frame_loop_ms", C.c_double), ("frames", C.c_int64), ("prefill_ms", C.c_double), ("gemv_ms", C.c_double),
                 ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double), ("codec_ms", C.c_double), ("codec_calls", C.c_int64),
                 ("talker_weight_bytes", C.c_double), ("predictor_weight_bytes", C.c_double), ("kv_bytes_per_token", C.c_double),
-                ("gu_ms", C.c_double), ("gu_launches", C.c_int64), ("gu_bytes", C.c_double)]
+                ("gu_ms", C.c_double), ("gu_launches", C.c_int64), ("gu_bytes", C.c_double),
+                ("sched_steps", C.c_int64), ("slot_frames", C.c_double)]
+
+
+class ReqStatus(C.Structure):
+    _fields_ = [("state", C.c_int32), ("n_frames", C.c_int32), ("n_pcm", C.c_int64), ("queue_ms", C.c_double),
+                ("prefill_ms", C.c_double), ("first_chunk_ms", C.c_double), ("total_ms", C.c_double)]
+
+
+REQ_QUEUED, REQ_RUNNING, REQ_DRAINING, REQ_DONE, REQ_FAILED = 0, 1, 2, 3, -1
 
 
 DECODE_CB = C.CFUNCTYPE(None, C.c_void_p, C.POINTER(C.c_int64), C.c_int32, C.c_int32)
@@ -53,7 +62,8 @@ SYMBOLS = [
     "q3tts_chunker_free", "q3tts_chunker_push", "q3tts_decoder_create", "q3tts_decoder_destroy", "q3tts_decoder_samples_per_frame",
     "q3tts_decoder_reset", "q3tts_decoder_decode", "q3tts_mel_frames", "q3tts_mel", "q3tts_tf_open", "q3tts_tf_close",
     "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
-    "q3tts_op_argmax", "q3tts_op_project",
+    "q3tts_op_argmax", "q3tts_op_project", "q3tts_op_sample", "q3tts_submit", "q3tts_poll", "q3tts_fetch", "q3tts_wait",
+    "q3tts_release", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
 ]
 
 
@@ -68,6 +78,18 @@ def lib():
         L.q3tts_engine_destroy.argtypes = [C.c_void_p]
         L.q3tts_generate_batch.argtypes = [C.c_void_p, C.POINTER(Request), C.c_int32, C.c_int32]
         L.q3tts_engine_stats.argtypes = [C.c_void_p, C.POINTER(Stats)]
+        L.q3tts_submit.argtypes = [C.c_void_p, C.POINTER(Request), C.c_int32, C.POINTER(C.c_int64)]
+        L.q3tts_poll.argtypes = [C.c_void_p, C.c_int64, C.POINTER(ReqStatus)]
+        L.q3tts_fetch.argtypes = [C.c_void_p, C.c_int64, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.c_int64,
+                                  C.POINTER(C.c_int32), C.POINTER(C.c_int64)]
+        L.q3tts_wait.argtypes = [C.c_void_p, C.c_int64, C.c_double]
+        L.q3tts_release.argtypes = [C.c_void_p, C.c_int64]
+        L.q3tts_sched_start.argtypes = [C.c_void_p]
+        L.q3tts_sched_stop.argtypes = [C.c_void_p]
+        L.q3tts_sched_step.argtypes = [C.c_void_p, C.POINTER(C.c_int32)]
+        L.q3tts_voice_register.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.POINTER(C.c_int32)]
+        L.q3tts_submit_text.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int32,
+                                        C.POINTER(SamplerConfig), C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_int64)]
         L.q3tts_engine_reset_stats.argtypes = [C.c_void_p]
         L.q3tts_engine_set_instrument.argtypes = [C.c_void_p, C.c_int32]
         L.q3tts_engine_bytes_per_step.restype = C.c_double
@@ -108,6 +130,7 @@ def lib():
         L.q3tts_op_rmsnorm_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.q3tts_op_swiglu_quant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.q3tts_op_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
+        L.q3tts_op_sample.argtypes = [C.c_void_p, C.c_int32, C.c_float, C.c_int32, C.c_float, C.c_uint64, C.c_int32, C.c_int32, C.c_void_p]
         L.q3tts_op_project.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p]
         _lib = L
     return _lib
@@ -241,26 +264,103 @@ class Engine:  # TtsEngine (engine.rs:53-169) at the embedding level
             lib().q3tts_engine_destroy(self.h)
         self.h = None
 
+    @staticmethod
+    def _per(v, i):
+        return v[i] if isinstance(v, (list, tuple, np.ndarray)) else v
+
+    def _fill(self, r, pr, i, max_steps, temperature, top_k, top_p, seed, mask_eos):
+        r.prompt = pr.ctypes.data
+        r.n_prompt = pr.shape[0]
+        r.sampler.temperature = self._per(temperature, i)
+        r.sampler.top_k = self._per(top_k, i)
+        r.sampler.top_p = self._per(top_p, i)
+        r.sampler.has_seed = 1
+        r.sampler.seed = self._per(seed, i)
+        r.max_steps = self._per(max_steps, i)
+        r.mask_eos = 1 if self._per(mask_eos, i) else 0
+
+    # ---- continuous-batching scheduler (q3tts_submit / poll / fetch / wait) ----
+    def submit(self, prompt, max_steps=8, temperature=0.0, top_k=40, top_p=0.9, seed=42, mask_eos=True, want_pcm=False):
+        pr = np.ascontiguousarray(prompt, np.float32)
+        r = Request()
+        self._fill(r, pr, 0, max_steps, temperature, top_k, top_p, seed, mask_eos)
+        rid = C.c_int64()
+        _chk(lib().q3tts_submit(self.h, C.byref(r), 1 if want_pcm else 0, C.byref(rid)))
+        return rid.value
+
+    def register_voice(self, spk_emb, ref_codes=None, ref_text_ids=None):
+        spk = np.ascontiguousarray(spk_emb, np.float32)
+        rc = np.ascontiguousarray(ref_codes, np.int32).reshape(-1) if ref_codes is not None else None
+        rt = np.ascontiguousarray(ref_text_ids, np.int32) if ref_text_ids is not None else None
+        vid = C.c_int32()
+        _chk(lib().q3tts_voice_register(self.h, _p(spk), _p(rc), rc.size if rc is not None else 0, _p(rt), rt.size if rt is not None else 0,
+                                        C.byref(vid)))
+        return vid.value
+
+    def submit_text(self, voice_id, text_ids, lang_id=2055, instr_ids=None, max_steps=8, temperature=0.0, top_k=40, top_p=0.9, seed=42,
+                    mask_eos=True, want_pcm=False):
+        t = np.ascontiguousarray(text_ids, np.int32)
+        ins = np.ascontiguousarray(instr_ids, np.int32) if instr_ids is not None else None
+        sc = SamplerConfig(temperature, top_k, top_p, 1, seed)
+        rid = C.c_int64()
+        _chk(lib().q3tts_submit_text(self.h, voice_id, _p(t), t.size, lang_id, _p(ins), ins.size if ins is not None else 0, C.byref(sc),
+                                     max_steps, 1 if mask_eos else 0, 1 if want_pcm else 0, C.byref(rid)))
+        return rid.value
+
+    def poll(self, rid):
+        s = ReqStatus()
+        _chk(lib().q3tts_poll(self.h, rid, C.byref(s)))
+        return {k: getattr(s, k) for k, _ in ReqStatus._fields_}
+
+    def fetch(self, rid, frame_off=0, max_frames=4096, pcm_off=0, pcm_cap=0):
+        codes = np.zeros(max(max_frames, 1) * 16, np.int32)
+        pcm = np.zeros(max(pcm_cap, 1), np.float32)
+        gf, gp = C.c_int32(), C.c_int64()
+        _chk(lib().q3tts_fetch(self.h, rid, _p(codes), frame_off, max_frames, _p(pcm) if pcm_cap > 0 else None, pcm_off, pcm_cap,
+                               C.byref(gf), C.byref(gp)))
+        return codes[: gf.value * 16].reshape(gf.value, 16).copy(), pcm[: gp.value].copy()
+
+    def wait(self, rid, timeout_ms=-1.0):
+        rc = lib().q3tts_wait(self.h, rid, timeout_ms)
+        if rc < 0:
+            _chk(rc)
+        return rc == 0
+
+    def release(self, rid):
+        _chk(lib().q3tts_release(self.h, rid))
+
+    def sched_start(self):
+        _chk(lib().q3tts_sched_start(self.h))
+
+    def sched_stop(self):
+        _chk(lib().q3tts_sched_stop(self.h))
+
+    def sched_step(self):
+        b = C.c_int32()
+        _chk(lib().q3tts_sched_step(self.h, C.byref(b)))
+        return bool(b.value)
+
+    def result(self, rid, want_pcm=False):
+        """collects a finished request (codes [n][16], pcm) and releases it"""
+        st = self.poll(rid)
+        codes, pcm = self.fetch(rid, 0, max(st["n_frames"], 1), 0, st["n_pcm"] if want_pcm else 0)
+        self.release(rid)
+        return {"codes": codes, "pcm": pcm if want_pcm else None, **st}
+
     def generate_batch(self, prompts, max_steps=8, temperature=0.0, top_k=40, top_p=0.9, seed=42, mask_eos=True, want_pcm=False,
                        pcm_per_frame=1920):
+        """per-request values may be given as lists (max_steps, temperature, top_k, top_p, seed, mask_eos)"""
         n = len(prompts)
         reqs = (Request * n)()
         keep = []
         for i, pr in enumerate(prompts):
             pr = np.ascontiguousarray(pr, np.float32)
-            codes = np.zeros(max_steps * 16, np.int32)
-            pcm = np.zeros(max(max_steps * pcm_per_frame, 1), np.float32) if want_pcm else None
+            ms = self._per(max_steps, i)
+            codes = np.zeros(max(ms, 1) * 16, np.int32)
+            pcm = np.zeros(max(ms * pcm_per_frame, 1), np.float32) if want_pcm else None
             keep.append((pr, codes, pcm))
             r = reqs[i]
-            r.prompt = pr.ctypes.data
-            r.n_prompt = pr.shape[0]
-            r.sampler.temperature = temperature
-            r.sampler.top_k = top_k
-            r.sampler.top_p = top_p
-            r.sampler.has_seed = 1
-            r.sampler.seed = seed
-            r.max_steps = max_steps
-            r.mask_eos = 1 if mask_eos else 0
+            self._fill(r, pr, i, max_steps, temperature, top_k, top_p, seed, mask_eos)
             r.codes_out = codes.ctypes.data
             r.pcm_out = pcm.ctypes.data if pcm is not None else None
             r.pcm_capacity = pcm.size if pcm is not None else 0
@@ -372,6 +472,13 @@ def op_argmax(logits, start, end, mask_idx=-1):
     out = np.zeros(1, np.int32)
     _chk(lib().q3tts_op_argmax(_p(logits), logits.size, start, end, mask_idx, _p(out)))
     return int(out[0])
+
+
+def op_sample(logits, temperature, top_k, top_p, seed, n_draws=1, mask_idx=-1):
+    logits = np.ascontiguousarray(logits, dtype=np.float32)
+    out = np.zeros(n_draws, dtype=np.int32)
+    _chk(lib().q3tts_op_sample(_p(logits), logits.size, temperature, top_k, top_p, seed, mask_idx, n_draws, _p(out)))
+    return out
 
 
 def op_project(x, w, b):

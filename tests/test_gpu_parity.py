@@ -85,6 +85,32 @@ def test_swiglu_argmax_project(gpu, oracle, tiny_model, vivian):
     oa.close()
 
 
+@pytest.mark.gpu
+def test_device_sampler_matches_oracle_sampler(gpu, oracle):
+    """k_sample (sort, top-k, softmax, top-p, ChaCha12 draw) vs the oracle's restatement of llama/mod.rs:666-776: same tokens"""
+    rng = np.random.default_rng(77)
+    cases = [(0.7, 40, 0.9), (1.0, 0, 1.0), (0.3, 5, 0.5), (1.5, 0, 0.95), (0.7, 1, 0.9), (0.05, 40, 0.9), (2.0, 3000, 0.999), (0.0, 40, 0.9)]
+    for ci, (t, k, p) in enumerate(cases):
+        for n in (2160, 300, 4096):
+            lg = (rng.standard_normal(n) * (1.0 + ci)).astype(np.float32)
+            tie = rng.integers(0, n, 12)
+            lg[tie] = lg.max()          # ties at the top exercise the stable order
+            lg[rng.integers(0, n, 5)] = -0.0
+            mask = int(tie[0]) if ci % 2 else -1
+            seed = 42 + ci
+            nd = 40                     # > 16 draws crosses a ChaCha block boundary
+            got = gpu.op_sample(lg, t, k, p, seed, n_draws=nd, mask_idx=mask)
+            ref = lg.copy()
+            if mask >= 0:
+                ref[mask] = -np.inf
+            exp, state = [], None
+            for _ in range(nd):
+                tok, state = oracle.sample(ref, 0, n, t, k, p, seed, state)
+                exp.append(tok)
+            exp = np.array(exp, np.int32)
+            assert np.array_equal(got, exp), (t, k, p, n, got[:8], exp[:8])
+
+
 def _tf_parity(gpu, oracle, path, d, n_pre, n_dec, rows):
     rng = np.random.default_rng(9)
     om = oracle.Model(path, 4096)
@@ -138,6 +164,11 @@ def test_attention_beyond_one_chunk(gpu, oracle, tiny_model):
     gm.close(); om.close()
 
 
+def gpu_mod():
+    import q3tts
+    return q3tts
+
+
 @pytest.fixture(scope="module")
 def tiny_engines(gpu, oracle, tiny_model):
     ge = gpu.Engine(tiny_model, "q8_0", max_batch=4, max_steps=64, load_codec=True)
@@ -156,7 +187,7 @@ def test_engine_matches_golden_and_oracle(tiny_engines, vivian):
     assert np.sqrt(np.mean((r["pcm"][:4096] - g["greedy_pcm_head"]) ** 2)) < PCM_RMS_TOL
     oc, opcm = oe.generate(prompt, max_steps=12, want_pcm=True)
     assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
-    # temperature > 0: host sampler on device logits (seeded StdRng stream)
+    # temperature > 0: device sampler inside the frame graph (seeded ChaCha12 stream)
     rs = ge.generate_batch([prompt], max_steps=12, temperature=0.7, top_k=40, top_p=0.9, seed=42, mask_eos=True)[0]
     assert np.array_equal(rs["codes"], g["sampled_codes"])
     # determinism
@@ -190,6 +221,67 @@ def test_engine_batch_equals_singles(tiny_engines, vivian):
         assert np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
     two = ge.generate_batch(prompts[:2], max_steps=10, mask_eos=True)
     assert all(np.array_equal(a["codes"], b["codes"]) for a, b in zip(two, batch))
+
+
+def test_scheduler_continuous_batching_matches_oracle(tiny_engines, vivian):
+    """BASELINE config 3 mechanics: 9 requests (ragged prompts, ragged lengths, greedy and sampled, natural EOS allowed) queue into
+    4 slots; sequences retire and new ones are admitted mid-flight.  Every request must equal the oracle run alone."""
+    ge, oe = tiny_engines
+    rng = np.random.default_rng(11)
+    specs = []
+    for i, (n_text, steps) in enumerate(((3, 5), (30, 17), (9, 8), (1, 12), (44, 4), (12, 9), (7, 0), (20, 13), (5, 6))):
+        prompt = ge.assets.build_core(rng.integers(0, 4000, n_text).astype(np.int32), lang_id=2055, spk_emb=vivian)
+        temp = 0.8 if i % 3 == 1 else 0.0
+        specs.append(dict(prompt=prompt, max_steps=steps, temperature=temp, top_k=(0 if i == 4 else 30), top_p=0.85, seed=100 + i,
+                          mask_eos=(i % 2 == 0), want_pcm=(i != 5)))
+    ids = [ge.submit(**sp) for sp in specs[:6]]
+    seen_partial = False
+    busy, it = True, 0
+    while busy:
+        busy = ge.sched_step()
+        it += 1
+        if it == 2:
+            ids += [ge.submit(**sp) for sp in specs[6:]]          # arrivals while the first wave is running
+            busy = True
+        st = ge.poll(ids[1])
+        if st["state"] == gpu_mod().REQ_RUNNING and st["n_frames"] > 0:
+            part, _ = ge.fetch(ids[1], 0, st["n_frames"])        # streaming read of a running request
+            seen_partial = seen_partial or part.shape[0] > 0
+    assert seen_partial
+    stats = ge.stats()
+    assert stats["sched_steps"] >= 4
+    for sp, rid in zip(specs, ids):
+        assert ge.poll(rid)["state"] == gpu_mod().REQ_DONE
+        r = ge.result(rid, want_pcm=sp["want_pcm"])
+        oc, opcm = oe.generate(sp["prompt"], max_steps=sp["max_steps"], temperature=sp["temperature"], top_k=sp["top_k"], top_p=sp["top_p"],
+                               seed=sp["seed"], mask_eos=sp["mask_eos"], want_pcm=sp["want_pcm"])
+        assert np.array_equal(oc, r["codes"]), (sp["max_steps"], sp["temperature"])
+        if sp["want_pcm"]:
+            assert r["pcm"].size == opcm.size and (opcm.size == 0 or np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL)
+
+
+def test_scheduler_driver_thread_and_voices(tiny_engines, vivian):
+    """background driver thread + voice registry: submit_text builds the preset / clone prompt engine-side (engine.rs:398-428)"""
+    ge, oe = tiny_engines
+    rng = np.random.default_rng(12)
+    ref_codes = rng.integers(0, 2048, 4 * 16).astype(np.int32)
+    ref_text = rng.integers(0, 4000, 3).astype(np.int32)
+    v_preset = ge.register_voice(vivian)
+    v_clone = ge.register_voice(vivian, ref_codes, ref_text)
+    texts = [rng.integers(0, 4000, n).astype(np.int32) for n in (6, 11, 4, 9, 15)]
+    ge.sched_start()
+    try:
+        ids = [ge.submit_text(v_clone if i % 2 else v_preset, t, lang_id=2055, max_steps=7 + i, want_pcm=True) for i, t in enumerate(texts)]
+        for rid in ids:
+            assert ge.wait(rid, 60000.0)
+    finally:
+        ge.sched_stop()
+    for i, (t, rid) in enumerate(zip(texts, ids)):
+        prompt = ge.assets.build_clone(t, ref_codes, ref_text, vivian) if i % 2 else ge.assets.build_core(t, lang_id=2055, spk_emb=vivian)
+        r = ge.result(rid, want_pcm=True)
+        assert r["first_chunk_ms"] > 0 and r["total_ms"] >= r["first_chunk_ms"]
+        oc, opcm = oe.generate(prompt, max_steps=7 + i, want_pcm=True)
+        assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
 
 
 def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
