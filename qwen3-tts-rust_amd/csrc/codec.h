@@ -10,7 +10,9 @@ namespace q3 {
 class CodecDecoder {
 public:
     // n_lanes: independent scratch sets so that decodes of different streams can run concurrently on different HIP streams
-    CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call, int n_lanes = 1);
+    // max_group: how many streams one pass may decode together (decode_group_async)
+    CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call, int n_lanes = 1, int max_group = 1);
+    int max_group() const;
     int n_lanes() const;
     ~CodecDecoder();
     int samples_per_frame() const;
@@ -19,6 +21,8 @@ public:
     int decode(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm);
     // same, but returns right after enqueueing: pcm_pinned must be hipHostMalloc'd and stay valid until `st` is synchronised
     int decode_async(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm_pinned, int lane = 0);
+    // G distinct streams, each with n_frames new frames: codes [G][n_frames][16], pcm[g] pinned destinations
+    int decode_group_async(hipStream_t st, int G, const int* streams, const int64_t* codes, int n_frames, float* const* pcm_pinned, int lane = 0);
     double flops_per_frame() const;
 private:
     struct Impl;

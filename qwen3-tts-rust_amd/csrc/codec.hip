@@ -26,14 +26,20 @@ struct GemmArgs {
     int epi; const float* res; int ldr; const float* scale; // EPI_RES_SCALE: out = res + scale[n]*(acc+bias); EPI_RES: res + acc+bias
     const float *snake_ea, *snake_ib;  // EPI_SNAKE: v + ib[n]*sin^2(v*ea[n]) applied to acc+bias
     float* ws;                          // split-K partial slabs [z][M][N]
+    // Batched decoding of G streams: row m belongs to segment m / segT.  A rows live in a batched extended buffer whose
+    // segments carry a_skip extra (history) rows each; out / res rows get o_skip / r_skip extra FLOATS per segment.
+    int a_segT, a_skip; int o_segT; long long o_skip; int r_segT; long long r_skip;
 };
+#define SEG_NONE 0x3fffffff
+
+__device__ __forceinline__ size_t out_off(const GemmArgs& g, int row, int col) { return (size_t)row * g.ldo + (size_t)(row / g.o_segT) * g.o_skip + col; }
 
 // epilogue shared by all GEMM forms: v = acc (+bias) -> activation / residual -> out
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col) {
     if (g.bias) v += g.bias[col];
     if (g.epi == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-    else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + col] + g.scale[col] * v;
-    else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + col] + v;
+    else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + (size_t)(row / g.r_segT) * g.r_skip + col] + g.scale[col] * v;
+    else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + (size_t)(row / g.r_segT) * g.r_skip + col] + v;
     else if (g.epi == EPI_SNAKE) { const float sn = sinf(v * g.snake_ea[col]); v = v + g.snake_ib[col] * (sn * sn); }
     return v;
 }
@@ -56,13 +62,16 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
 #pragma unroll
     for (int i = 0; i < 16; i++) acc[i] = 0.0f;
     float4 ra[NA], rb[NB];
+    int arow[NA]; // A row of this thread's i-th fetch (tap 0), including the history rows of the segments before it
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) % BM; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e % BM, qd = e / BM;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < BM * 4 && m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(m0 + r + j * g.dil) * g.lda + ci0 + 4 * qd);
+            if (e < BM * 4 && m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * qd);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
@@ -103,7 +112,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < g.M) {
                 if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
-                else g.out[(size_t)row * g.ldo + col] = gemm_epilogue(g, acc[r], row, col);
+                else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[r], row, col);
             }
         }
     }
@@ -114,7 +123,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const int row = (int)(i / g.N), col = (int)(i % g.N);
     float v = g.ws[i];
     for (int s = 1; s < ksplit; s++) v += g.ws[(size_t)s * g.M * g.N + i];
-    g.out[(size_t)row * g.ldo + col] = gemm_epilogue(g, v, row, col);
+    g.out[out_off(g, row, col)] = gemm_epilogue(g, v, row, col);
 }
 
 // Skinny GEMM for M <= 16 (transformer, ConvNeXt MLPs, conv_in, first transposed conv): weights are streamed exactly
@@ -144,7 +153,7 @@ __global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < g.M && kk < kt) {
                 const int kg = k0 + kk, j = kg / g.cin, ci = kg % g.cin;
-                v = *reinterpret_cast<const float4*>(g.A + (size_t)(m + j * g.dil) * g.lda + ci);
+                v = *reinterpret_cast<const float4*>(g.A + (size_t)(m + (m / g.a_segT) * g.a_skip + j * g.dil) * g.lda + ci);
             }
             *reinterpret_cast<float4*>(&As[m][kk]) = v;
         }
@@ -166,7 +175,7 @@ __global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
         if (lane == m) mine = v;
     }
-    if (lane < MT && lane < g.M && n < g.N) g.out[(size_t)lane * g.ldo + n] = gemm_epilogue(g, mine, lane, n);
+    if (lane < MT && lane < g.M && n < g.N) g.out[out_off(g, lane, n)] = gemm_epilogue(g, mine, lane, n);
 }
 static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats) {
     if (g.M <= 16) {
@@ -191,8 +200,14 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats) {
 }
 
 // ---------------- small elementwise / reduction kernels ----------------
+// Row maps: a batched extended buffer holds G segments of (H + T) rows; logical row r (= g*T + t) lives at physical row
+// r + (r / segT) * skip + off  (segT = T, skip = H, off = 0 for the "history first" view, off = H for the "current rows" view).
+struct RowMap { int segT, skip, off; };
+__device__ __forceinline__ size_t map_row(const RowMap& m, int r) { return (size_t)r + (size_t)(r / m.segT) * m.skip + m.off; }
+static RowMap plain_map() { return RowMap{SEG_NONE, 0, 0}; }
+
 __global__ void k_rvq_sum(const int64_t* __restrict__ codes, const float* const* __restrict__ cb, int n_q, int cb_size, int cb_dim,
-                          float* __restrict__ out, int ldo) {
+                          float* __restrict__ out, int ldo, RowMap om) {
     const int t = blockIdx.y, d = blockIdx.x * 256 + threadIdx.x;
     if (d >= cb_dim) return;
     float acc = 0.0f;
@@ -201,7 +216,7 @@ __global__ void k_rvq_sum(const int64_t* __restrict__ codes, const float* const*
         c = c < 0 ? 0 : (c >= cb_size ? cb_size - 1 : c);
         acc += cb[q][(size_t)c * cb_dim + d];
     }
-    out[(size_t)t * ldo + d] = acc;
+    out[map_row(om, t) * ldo + d] = acc;
 }
 __global__ void __launch_bounds__(256) k_rmsnorm_rows(const float* __restrict__ x, int ldx, const float* __restrict__ g, int C, float eps,
                                                       float* __restrict__ y, int ldy) {
@@ -235,41 +250,48 @@ __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict_
     const float inv = 1.0f / sqrtf(var + eps);
     for (int c = threadIdx.x; c < C; c += 256) y[(size_t)t * ldy + c] = (x[(size_t)t * ldx + c] - mu) * inv * w[c] + b[c];
 }
-// NeoX RoPE on q and k inside a packed [T][3*H] qkv buffer (head_dim hd), absolute position pos0 + t
+// per-call stream metadata on device: meta[0..G) = stream index, meta[G..2G) = valid K/V history rows, meta[2G..3G) = frames seen
+// NeoX RoPE on q and k inside a packed [G*T0][3*H] qkv buffer (head_dim hd), absolute position seen[g] + t
 __global__ void k_codec_rope(float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ cs, const float* __restrict__ sn,
-                             long long pos0, int max_pos) {
-    const int t = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, half = hd / 2;
+                             const int64_t* __restrict__ meta, int G, int T0, int max_pos) {
+    const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, half = hd / 2;
     if (e >= H / 2) return;
     const int head = e / half, i = e % half;
-    long long p = pos0 + t;
+    long long p = meta[2 * G + r / T0] + (r % T0);
     if (p >= max_pos) p = max_pos - 1;
     const float c = cs[(size_t)p * half + i], s = sn[(size_t)p * half + i];
     for (int which = 0; which < 2; which++) {
-        float* v = qkv + (size_t)t * ld + which * H + head * hd;
+        float* v = qkv + (size_t)r * ld + which * H + head * hd;
         const float a = v[i], b = v[i + half];
         v[i] = a * c - b * s; v[i + half] = b * c + a * s;
     }
 }
-// append new K,V rows to the layer's history buffers: kbuf/vbuf [(W-1)+Tmax][H]
-__global__ void k_kv_append(const float* __restrict__ qkv, int ld, int H, float* __restrict__ kbuf, float* __restrict__ vbuf, int kv_len) {
-    const int t = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
+// append new K,V rows to the batched K/V extended buffers (segment = (W-1) history rows + T0 new rows)
+__global__ void k_kv_append(const float* __restrict__ qkv, int ld, int H, float* __restrict__ kext, float* __restrict__ vext, RowMap om) {
+    const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= H) return;
-    kbuf[(size_t)(kv_len + t) * H + c] = qkv[(size_t)t * ld + H + c];
-    vbuf[(size_t)(kv_len + t) * H + c] = qkv[(size_t)t * ld + 2 * H + c];
+    const size_t o = map_row(om, r) * H + c;
+    kext[o] = qkv[(size_t)r * ld + H + c];
+    vext[o] = qkv[(size_t)r * ld + 2 * H + c];
 }
-// sliding-window attention: one wave per (head, t); keys j in [max(0, kv_len+t-W+1), kv_len+t]
-__global__ void __launch_bounds__(64) k_codec_attn(const float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ kbuf,
-                                                   const float* __restrict__ vbuf, int kv_len, int W, float* __restrict__ out, int ldo) {
+// sliding-window attention: one wave per (head, row); the segment of stream g holds its W-1 history rows RIGHT-aligned
+// (only the last kvlen[g] are valid) followed by the T0 new rows; keys of row t: max(t, W-1-kvlen) .. W-1+t
+__global__ void __launch_bounds__(64) k_codec_attn(const float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ kext,
+                                                   const float* __restrict__ vext, const int64_t* __restrict__ meta, int G, int T0, int W,
+                                                   float* __restrict__ out, int ldo) {
     __shared__ float p_s[128];
     __shared__ float q_s[128];
-    const int head = blockIdx.x, t = blockIdx.y, lane = threadIdx.x;
-    const int j1 = kv_len + t, j0 = (j1 - (W - 1)) > 0 ? (j1 - (W - 1)) : 0, nk = j1 - j0 + 1;
-    for (int d = lane; d < hd; d += 64) q_s[d] = qkv[(size_t)t * ld + head * hd + d];
+    const int head = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    const int g = r / T0, t = r % T0;
+    const int kvl = (int)meta[G + g];
+    const size_t seg = (size_t)g * (W - 1 + T0);
+    const int j1 = W - 1 + t, jv = W - 1 - kvl, j0 = t > jv ? t : jv, nk = j1 - j0 + 1;
+    for (int d = lane; d < hd; d += 64) q_s[d] = qkv[(size_t)r * ld + head * hd + d];
     __syncthreads();
     const float scale = 1.0f / sqrtf((float)hd);
     float mx = -INFINITY;
     for (int jj = lane; jj < nk; jj += 64) {
-        const float* kr = kbuf + (size_t)(j0 + jj) * H + head * hd;
+        const float* kr = kext + (seg + j0 + jj) * H + head * hd;
         float a = 0.0f;
         for (int d = 0; d < hd; d++) a += q_s[d] * kr[d];
         a *= scale;
@@ -283,8 +305,8 @@ __global__ void __launch_bounds__(64) k_codec_attn(const float* __restrict__ qkv
     __syncthreads();
     for (int d = lane; d < hd; d += 64) {
         float a = 0.0f;
-        for (int jj = 0; jj < nk; jj++) a += p_s[jj] * vbuf[(size_t)(j0 + jj) * H + head * hd + d];
-        out[(size_t)t * ldo + head * hd + d] = a / den;
+        for (int jj = 0; jj < nk; jj++) a += p_s[jj] * vext[(seg + j0 + jj) * H + head * hd + d];
+        out[(size_t)r * ldo + head * hd + d] = a / den;
     }
 }
 __global__ void k_swiglu_rows(const float* __restrict__ gu, int ff, float* __restrict__ out) { // gu [T][2ff] -> out [T][ff]
@@ -293,49 +315,64 @@ __global__ void k_swiglu_rows(const float* __restrict__ gu, int ff, float* __res
     const float g = gu[(size_t)t * 2 * ff + c], u = gu[(size_t)t * 2 * ff + ff + c];
     out[(size_t)t * ff + c] = (g / (1.0f + expf(-g))) * u;
 }
-// depthwise causal conv k=7: in_ext [6+T][C], w [C][7]
+// depthwise causal conv k=7 over a batched extended buffer (6 history rows per segment), w [C][7]; out plain rows
 __global__ void k_dwconv7(const float* __restrict__ in_ext, int C, const float* __restrict__ w, const float* __restrict__ b,
-                          float* __restrict__ out) {
+                          float* __restrict__ out, RowMap im) {
     const int t = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
     if (c >= C) return;
+    const size_t r0 = map_row(im, t);
     float a = b[c];
 #pragma unroll
-    for (int j = 0; j < 7; j++) a += w[c * 7 + j] * in_ext[(size_t)(t + j) * C + c];
+    for (int j = 0; j < 7; j++) a += w[c * 7 + j] * in_ext[(r0 + j) * C + c];
     out[(size_t)t * C + c] = a;
 }
-// y = x + inv_eb[c] * sin^2(x*ea[c]); src [T][C] -> dst rows (dst may equal src)
+// y = x + inv_eb[c] * sin^2(x*ea[c]); src plain rows [T][C] -> dst rows through the map
 __global__ void k_snake(const float* __restrict__ src, float* __restrict__ dst, int C, const float* __restrict__ ea,
-                        const float* __restrict__ inv_eb, size_t n) {
+                        const float* __restrict__ inv_eb, size_t n, RowMap dm) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    const int c = (int)(i % C);
+    const int c = (int)(i % C), r = (int)(i / C);
     const float v = src[i];
     const float s = sinf(v * ea[c]);
-    dst[i] = v + inv_eb[c] * (s * s);
+    dst[map_row(dm, r) * C + c] = v + inv_eb[c] * (s * s);
 }
-__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, size_t n) {
+__global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, size_t n, int C, RowMap dm) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) dst[i] = src[i];
+    if (i >= n) return;
+    const int c = (int)(i % C), r = (int)(i / C);
+    dst[map_row(dm, r) * C + c] = src[i];
+}
+// streaming state: history rows of segment g <-> the owning stream's slot in the per-conv state store [n_streams][H][C]
+__global__ void k_hist_load(float* __restrict__ ext, const float* __restrict__ hist, const int64_t* __restrict__ meta, int H, int C, int T) {
+    const int g = blockIdx.y;
+    const size_t n = (size_t)H * C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    ext[(size_t)g * (H + T) * C + i] = hist[(size_t)meta[g] * n + i];
+}
+__global__ void k_hist_save(const float* __restrict__ ext, float* __restrict__ hist, const int64_t* __restrict__ meta, int H, int C, int T) {
+    const int g = blockIdx.y; // the last H rows of (history + new rows) become the next call's history
+    const size_t n = (size_t)H * C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    hist[(size_t)meta[g] * n + i] = ext[((size_t)g * (H + T) + T) * C + i];
 }
 // final conv (cout = 1): out[t] = clamp(b + sum_{j,c} w[j*C+c] * in_ext[t+j][c])
 __global__ void __launch_bounds__(256) k_conv_out(const float* __restrict__ in_ext, int C, const float* __restrict__ w, float bias,
-                                                  float* __restrict__ pcm, int T) {
+                                                  float* __restrict__ pcm, int n, RowMap im) {
     const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t >= T) return;
+    if (t >= n) return;
+    const size_t r0 = map_row(im, t);
     float a = bias;
     for (int j = 0; j < 7; j++)
-        for (int c = 0; c < C; c++) a += w[j * C + c] * in_ext[(size_t)(t + j) * C + c];
+        for (int c = 0; c < C; c++) a += w[j * C + c] * in_ext[(r0 + j) * C + c];
     pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
 }
 
 // ---------------- host side ----------------
 struct ConvW { DevBuf<float> w, b; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
 struct Snake { DevBuf<float> ea, inv_eb; int C = 0; };
-struct Ext { // per-stream extended activation buffer: H history rows then up to Tmax rows of C floats
-    std::vector<DevBuf<float>> buf; int H = 0, C = 0, Tmax = 0;
-    float* base(int s) { return buf[s].p; }
-    float* cur(int s) { return buf[s].p + (size_t)H * C; }
-};
+// A causal conv's streaming state.  `hist` is the persistent store [n_streams][H][C]; the rows a call works on live in a
+// per-lane batched extended buffer [G][(H + T)][C] (Scratch::work[id]): history first, then the call's T new rows.
+struct Ext { DevBuf<float> hist; int H = 0, C = 0, Tmax = 0, id = -1; };
 
 struct CodecDecoder::Impl {
     int n_q, cb_size, cb_dim, hidden, n_layers, n_heads, head_dim, ffn, window, n_up, dec_dim, n_dec;
@@ -354,15 +391,17 @@ struct CodecDecoder::Impl {
     std::vector<Blk> blk;
     Snake snake_out; DevBuf<float> conv_out_w; float conv_out_b = 0;
     // per-stream state
-    Ext z_ext, convin_ext, out_ext; std::vector<Ext> dw_ext, ct_ext; std::vector<std::vector<Ext>> ru_ext;
-    std::vector<std::vector<DevBuf<float>>> kbuf, vbuf; // [stream][layer]
+    Ext z_ext, convin_ext, out_ext; std::vector<Ext> dw_ext, ct_ext, k_ext, v_ext; std::vector<std::vector<Ext>> ru_ext;
+    std::vector<Ext*> all_ext;
     std::vector<int> kv_len; std::vector<long long> n_seen;
-    // scratch (shared by streams; one decode at a time)
+    int gmax = 1; // streams decoded together in one pass
     struct Scratch { // one set per concurrency lane: independent decodes run on different HIP streams at the same time
-        DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, tmp_hist, pcm, splitk_ws; DevBuf<int64_t> d_codes;
-        int64_t* h_codes = nullptr; int ring_idx = 0; // pinned staging ring for the (tiny) code uploads of async calls
+        DevBuf<float> h, xn, qkv, att, gu, act, t1, t2, pcm, splitk_ws; DevBuf<int64_t> d_in; // d_in = codes then meta
+        std::vector<DevBuf<float>> work;              // batched extended buffers, indexed by Ext::id
+        int64_t* h_in = nullptr; int ring_idx = 0;    // pinned staging ring for the (tiny) code + metadata uploads of async calls
     };
     std::vector<Scratch> lanes; Scratch* S = nullptr; int ring = 256;
+    size_t in_slot() const { return (size_t)gmax * max_frames * n_q + 3 * (size_t)gmax; }
     double flops_frame = 0;
 
     static std::vector<float> tensor(const Gguf& g, const std::string& name) {
@@ -410,39 +449,54 @@ struct CodecDecoder::Impl {
         up_f(s.ea, ea); up_f(s.inv_eb, ib); s.C = C;
     }
     void make_ext(Ext& e, int H, int C, int Tmax) {
-        e.H = H; e.C = C; e.Tmax = Tmax;
-        e.buf.resize(n_streams);
-        for (auto& b : e.buf) { b.alloc((size_t)(H + Tmax) * C); b.zero(); }
+        e.H = H; e.C = C; e.Tmax = Tmax; e.id = (int)all_ext.size();
+        e.hist.alloc((size_t)n_streams * H * C); e.hist.zero();
+        all_ext.push_back(&e);
     }
-    void run_conv(hipStream_t st, const ConvW& c, const float* A, int lda, int M, float* out, int ldo, int epi = EPI_NONE,
-                  const float* res = nullptr, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr) {
+    // where a GEMM operand lives: a plain [M][ld] buffer, or the batched extended buffer of `e` for a call with T rows per stream
+    struct Loc { float* p; int segT; long long skip_rows; };
+    Loc plain(float* p) { return Loc{p, SEG_NONE, 0}; }
+    float* work(const Ext& e) { return S->work[e.id].p; }
+    Loc ext_base(const Ext& e, int T) { return Loc{work(e), T, e.H}; }                       // rows t + j*dil, history first
+    Loc ext_cur(const Ext& e, int T) { return Loc{work(e) + (size_t)e.H * e.C, T, e.H}; }   // the call's new rows
+    RowMap cur_map(const Ext& e, int T) { return RowMap{T, e.H, e.H}; }
+    RowMap base_map(const Ext& e, int T) { return RowMap{T, e.H, 0}; }
+    // out_rows_per_m: a transposed conv writes f consecutive C-wide rows per GEMM row (ldo = f*C); skip stays H*C floats per segment
+    void run_conv(hipStream_t st, const ConvW& c, Loc A, int lda, int M, Loc out, int ldo, int out_C, int epi = EPI_NONE,
+                  Loc res = Loc{nullptr, SEG_NONE, 0}, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr) {
         GemmArgs g{};
-        g.A = A; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out; g.ldo = ldo;
-        g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res; g.ldr = ldr; g.scale = scale;
+        g.A = A.p; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out.p; g.ldo = ldo;
+        g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res.p; g.ldr = ldr; g.scale = scale;
+        g.a_segT = A.segT; g.a_skip = (int)A.skip_rows;
+        g.o_segT = out.segT; g.o_skip = out.skip_rows * out_C;
+        g.r_segT = res.segT; g.r_skip = res.skip_rows * ldr;
         if (sn) { g.snake_ea = sn->ea.p; g.snake_ib = sn->inv_eb.p; }
         gemm(st, g, S->splitk_ws.p, S->splitk_ws.n);
     }
-    // move the last H rows of an extended buffer (rows [T, T+H)) to its front
-    void shift(hipStream_t st, Ext& e, int s, int T) {
+    void load_hist(hipStream_t st, const Ext& e, int G, int T, const int64_t* meta) {
         if (e.H == 0) return;
         const size_t n = (size_t)e.H * e.C;
-        float* b = e.base(s);
-        if (T >= e.H) hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, b, n);
-        else {
-            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b + (size_t)T * e.C, S->tmp_hist.p, n);
-            hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, S->tmp_hist.p, b, n);
-        }
+        hipLaunchKernelGGL(k_hist_load, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, st, work(e), e.hist.p, meta, e.H, e.C, T);
     }
-    void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int T) {
-        const size_t n = (size_t)T * s.C;
-        hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n);
+    void save_hist(hipStream_t st, Ext& e, int G, int T, const int64_t* meta) {
+        if (e.H == 0) return;
+        const size_t n = (size_t)e.H * e.C;
+        hipLaunchKernelGGL(k_hist_save, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, st, work(e), e.hist.p, meta, e.H, e.C, T);
+    }
+    void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int rows, RowMap dm) {
+        const size_t n = (size_t)rows * s.C;
+        hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n, dm);
+    }
+    void copy_rows(hipStream_t st, const float* src, float* dst, int rows, int C, RowMap dm) {
+        const size_t n = (size_t)rows * C;
+        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, n, C, dm);
     }
 };
 
-CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes) : impl_(new Impl()) {
+CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes, int max_group) : impl_(new Impl()) {
     Impl& m = *impl_;
     Gguf g(path);
-    m.n_streams = n_streams; m.max_frames = max_frames;
+    m.n_streams = n_streams; m.max_frames = max_frames; m.gmax = max_group > 0 ? max_group : 1;
     m.n_q = (int)g.kv_int("codec.n_codebooks", 16); m.cb_size = (int)g.kv_int("codec.codebook_size", 2048);
     m.cb_dim = (int)g.kv_int("codec.codebook_dim", 512); m.hidden = (int)g.kv_int("codec.hidden", 1024);
     m.n_layers = (int)g.kv_int("codec.n_layers", 8); m.n_heads = (int)g.kv_int("codec.n_heads", 16);
@@ -539,45 +593,47 @@ CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frame
     }
     m.flops_frame = fl;
     // ---- per-stream state + scratch ----
-    const int T0 = max_frames;
+    const int T0 = max_frames, GM = m.gmax;
     m.make_ext(m.z_ext, 2, m.cb_dim, T0);
+    m.k_ext.resize(m.n_layers); m.v_ext.resize(m.n_layers);
+    for (int l = 0; l < m.n_layers; l++) { m.make_ext(m.k_ext[l], m.window - 1, H, T0); m.make_ext(m.v_ext[l], m.window - 1, H, T0); }
     int T = T0;
     m.dw_ext.resize(m.n_up);
     for (int i = 0; i < m.n_up; i++) { T *= m.up_ratios[i]; m.make_ext(m.dw_ext[i], 6, H, T); }
     const int Tlat = T;
     m.make_ext(m.convin_ext, 6, H, Tlat);
     m.ct_ext.resize(m.n_dec); m.ru_ext.resize(m.n_dec);
-    size_t max_act = (size_t)Tlat * 4 * H, max_hist = (size_t)6 * H;
+    size_t max_act = (size_t)Tlat * 4 * H;
     ch = m.dec_dim;
     static const int dil[3] = {1, 3, 9};
     for (int b = 0; b < m.n_dec; b++) {
         m.make_ext(m.ct_ext[b], 1, ch, T);
         T *= m.dec_rates[b]; ch /= 2;
         m.ru_ext[b].resize(3);
-        for (int u = 0; u < 3; u++) { m.make_ext(m.ru_ext[b][u], 6 * dil[u], ch, T); max_hist = std::max(max_hist, (size_t)6 * dil[u] * ch); }
+        for (int u = 0; u < 3; u++) m.make_ext(m.ru_ext[b][u], 6 * dil[u], ch, T);
         max_act = std::max(max_act, (size_t)T * ch);
     }
     m.make_ext(m.out_ext, 6, ch, T);
     max_act = std::max(max_act, (size_t)Tlat * m.dec_dim);
-    m.kbuf.resize(n_streams); m.vbuf.resize(n_streams);
-    for (int s = 0; s < n_streams; s++) {
-        m.kbuf[s].resize(m.n_layers); m.vbuf[s].resize(m.n_layers);
-        for (int l = 0; l < m.n_layers; l++) { m.kbuf[s][l].alloc((size_t)(m.window + T0) * H); m.vbuf[s][l].alloc((size_t)(m.window + T0) * H); m.kbuf[s][l].zero(); m.vbuf[s][l].zero(); }
-    }
+    max_act *= GM;
     m.kv_len.assign(n_streams, 0); m.n_seen.assign(n_streams, 0);
     m.lanes.resize(n_lanes > 0 ? n_lanes : 1);
     for (auto& L : m.lanes) {
-        L.h.alloc((size_t)T0 * H); L.xn.alloc((size_t)T0 * H); L.qkv.alloc((size_t)T0 * 3 * H); L.att.alloc((size_t)T0 * H);
-        L.gu.alloc((size_t)T0 * 2 * m.ffn); L.act.alloc((size_t)T0 * m.ffn);
-        L.t1.alloc(max_act); L.t2.alloc(max_act); L.tmp_hist.alloc(std::max(max_hist, (size_t)(m.window + T0) * H)); L.pcm.alloc((size_t)T);
-        L.d_codes.alloc((size_t)T0 * m.n_q);
-        L.splitk_ws.alloc(std::max<size_t>(max_act * 4, (size_t)1 << 20));
-        Q3_HIP(hipHostMalloc((void**)&L.h_codes, (size_t)m.ring * T0 * m.n_q * sizeof(int64_t)));
+        const size_t R0 = (size_t)GM * T0;
+        L.h.alloc(R0 * H); L.xn.alloc(R0 * H); L.qkv.alloc(R0 * 3 * H); L.att.alloc(R0 * H);
+        L.gu.alloc(R0 * 2 * m.ffn); L.act.alloc(R0 * m.ffn);
+        L.t1.alloc(max_act); L.t2.alloc(max_act); L.pcm.alloc((size_t)GM * T);
+        L.work.resize(m.all_ext.size());
+        for (Ext* e : m.all_ext) L.work[e->id].alloc((size_t)GM * (e->H + e->Tmax) * e->C);
+        L.d_in.alloc(m.in_slot());
+        L.splitk_ws.alloc(std::max<size_t>(max_act * 2, (size_t)1 << 20));
+        Q3_HIP(hipHostMalloc((void**)&L.h_in, (size_t)m.ring * m.in_slot() * sizeof(int64_t)));
     }
     m.S = &m.lanes[0];
     Q3_HIP(hipDeviceSynchronize());
 }
-CodecDecoder::~CodecDecoder() { if (impl_) for (auto& L : impl_->lanes) if (L.h_codes) (void)hipHostFree(L.h_codes); }
+CodecDecoder::~CodecDecoder() { if (impl_) for (auto& L : impl_->lanes) if (L.h_in) (void)hipHostFree(L.h_in); }
+int CodecDecoder::max_group() const { return impl_->gmax; }
 int CodecDecoder::n_lanes() const { return (int)impl_->lanes.size(); }
 int CodecDecoder::samples_per_frame() const {
     int s = 1;
@@ -590,11 +646,7 @@ double CodecDecoder::flops_per_frame() const { return impl_->flops_frame; }
 void CodecDecoder::reset(int s) {
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
-    auto z = [&](Ext& e) { Q3_HIP(hipMemset(e.base(s), 0, (size_t)e.H * e.C * 4)); };
-    z(m.z_ext); z(m.convin_ext); z(m.out_ext);
-    for (auto& e : m.dw_ext) z(e);
-    for (auto& e : m.ct_ext) z(e);
-    for (auto& v : m.ru_ext) for (auto& e : v) z(e);
+    for (Ext* e : m.all_ext) if (e->H) Q3_HIP(hipMemset(e->hist.p + (size_t)s * e->H * e->C, 0, (size_t)e->H * e->C * 4));
     m.kv_len[s] = 0; m.n_seen[s] = 0;
 }
 
@@ -603,110 +655,122 @@ int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_fram
     Q3_HIP(hipStreamSynchronize(st));
     return T;
 }
-
 int CodecDecoder::decode_async(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm, int lane) {
     (void)is_last; // causal stack: nothing is held back (valid_samples == everything)
-    Impl& mm = *impl_;
-    Q3_CHECK(lane >= 0 && lane < (int)mm.lanes.size(), "codec lane out of range");
-    mm.S = &mm.lanes[lane];
-    struct View : Impl::Scratch {}; // scratch members are reached through m.S below
-    Impl& m = mm;
-    Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
+    return decode_group_async(st, 1, &s, codes, n_frames, &pcm, lane);
+}
+
+// One pass for G streams that each contribute n_frames new frames: every GEMM runs over G*T rows, so the 733 MB of
+// codec weights are streamed once per group instead of once per stream, and one set of launches serves the group.
+int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, const int64_t* codes, int n_frames, float* const* pcm, int lane) {
+    Impl& m = *impl_;
+    Q3_CHECK(lane >= 0 && lane < (int)m.lanes.size(), "codec lane out of range");
+    Q3_CHECK(G >= 1 && G <= m.gmax, "group size out of range");
+    m.S = &m.lanes[lane];
     if (n_frames <= 0) return 0;
     Q3_CHECK(n_frames <= m.max_frames, "too many frames per decode call");
-    const int H = m.hidden, T0 = n_frames;
+    for (int g = 0; g < G; g++) {
+        Q3_CHECK(streams[g] >= 0 && streams[g] < m.n_streams, "stream out of range");
+        for (int h = 0; h < g; h++) Q3_CHECK(streams[h] != streams[g], "a stream may appear once per group");
+    }
+    const int H = m.hidden, T0 = n_frames, R0 = G * T0, W = m.window;
     if (m.S->ring_idx == m.ring) { Q3_HIP(hipStreamSynchronize(st)); m.S->ring_idx = 0; } // all earlier uploads have been consumed
-    int64_t* hc = m.S->h_codes + (size_t)(m.S->ring_idx++) * m.max_frames * m.n_q;
-    std::copy(codes, codes + (size_t)T0 * m.n_q, hc);
-    Q3_HIP(hipMemcpyAsync(m.S->d_codes.p, hc, (size_t)T0 * m.n_q * 8, hipMemcpyHostToDevice, st));
+    int64_t* hin = m.S->h_in + (size_t)(m.S->ring_idx++) * m.in_slot();
+    const size_t ncodes = (size_t)R0 * m.n_q;
+    std::copy(codes, codes + ncodes, hin);
+    for (int g = 0; g < G; g++) { hin[ncodes + g] = streams[g]; hin[ncodes + G + g] = m.kv_len[streams[g]]; hin[ncodes + 2 * G + g] = m.n_seen[streams[g]]; }
+    Q3_HIP(hipMemcpyAsync(m.S->d_in.p, hin, (ncodes + 3 * (size_t)G) * 8, hipMemcpyHostToDevice, st));
+    const int64_t* d_codes = m.S->d_in.p;
+    const int64_t* meta = m.S->d_in.p + ncodes;
     // 1. RVQ sum -> z_ext current rows ; 2. pre_conv
-    hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, T0), dim3(256), 0, st, m.S->d_codes.p, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
-                       m.z_ext.cur(s), m.cb_dim);
-    m.run_conv(st, m.pre_conv, m.z_ext.base(s), m.cb_dim, T0, m.S->h.p, H);
-    m.shift(st, m.z_ext, s, T0);
+    m.load_hist(st, m.z_ext, G, T0, meta);
+    hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, R0), dim3(256), 0, st, d_codes, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
+                       m.work(m.z_ext), m.cb_dim, m.cur_map(m.z_ext, T0));
+    m.run_conv(st, m.pre_conv, m.ext_base(m.z_ext, T0), m.cb_dim, R0, m.plain(m.S->h.p), H, H);
+    m.save_hist(st, m.z_ext, G, T0, meta);
     // 3. transformer
-    const int kvl = m.kv_len[s];
     for (int l = 0; l < m.n_layers; l++) {
         auto& L = m.tf[l];
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, L.attn_norm.p, H, m.eps, m.S->xn.p, H);
-        m.run_conv(st, L.wqkv, m.S->xn.p, H, T0, m.S->qkv.p, 3 * H);
-        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, T0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
-                           m.n_seen[s], m.max_pos);
-        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, T0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl);
-        hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, T0), dim3(64), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.kbuf[s][l].p, m.vbuf[s][l].p, kvl,
-                           m.window, m.S->att.p, H);
-        m.run_conv(st, L.wo, m.S->att.p, H, T0, m.S->h.p, H, EPI_RES_SCALE, m.S->h.p, H, L.ls_attn.p);
-        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, L.ffn_norm.p, H, m.eps, m.S->xn.p, H);
-        m.run_conv(st, L.wgu, m.S->xn.p, H, T0, m.S->gu.p, 2 * m.ffn);
-        hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, T0), dim3(256), 0, st, m.S->gu.p, m.ffn, m.S->act.p);
-        m.run_conv(st, L.wdown, m.S->act.p, m.ffn, T0, m.S->h.p, H, EPI_RES_SCALE, m.S->h.p, H, L.ls_ffn.p);
-        // keep the last window-1 positions as history
-        const int tot = kvl + T0, keep = tot < m.window - 1 ? tot : m.window - 1;
-        if (tot > keep) {
-            const size_t n = (size_t)keep * H;
-            for (DevBuf<float>* b : {&m.kbuf[s][l], &m.vbuf[s][l]}) {
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, b->p + (size_t)(tot - keep) * H, m.S->tmp_hist.p, n);
-                hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, m.S->tmp_hist.p, b->p, n);
-            }
-        }
+        Ext &ke = m.k_ext[l], &ve = m.v_ext[l];
+        m.load_hist(st, ke, G, T0, meta); m.load_hist(st, ve, G, T0, meta);
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(R0), dim3(256), 0, st, m.S->h.p, H, L.attn_norm.p, H, m.eps, m.S->xn.p, H);
+        m.run_conv(st, L.wqkv, m.plain(m.S->xn.p), H, R0, m.plain(m.S->qkv.p), 3 * H, 3 * H);
+        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
+                           meta, G, T0, m.max_pos);
+        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.work(ke), m.work(ve), m.cur_map(ke, T0));
+        hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, R0), dim3(64), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.work(ke), m.work(ve), meta, G, T0, W,
+                           m.S->att.p, H);
+        m.run_conv(st, L.wo, m.plain(m.S->att.p), H, R0, m.plain(m.S->h.p), H, H, EPI_RES_SCALE, m.plain(m.S->h.p), H, L.ls_attn.p);
+        hipLaunchKernelGGL(k_rmsnorm_rows, dim3(R0), dim3(256), 0, st, m.S->h.p, H, L.ffn_norm.p, H, m.eps, m.S->xn.p, H);
+        m.run_conv(st, L.wgu, m.plain(m.S->xn.p), H, R0, m.plain(m.S->gu.p), 2 * m.ffn, 2 * m.ffn);
+        hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, R0), dim3(256), 0, st, m.S->gu.p, m.ffn, m.S->act.p);
+        m.run_conv(st, L.wdown, m.plain(m.S->act.p), m.ffn, R0, m.plain(m.S->h.p), H, H, EPI_RES_SCALE, m.plain(m.S->h.p), H, L.ls_ffn.p);
+        m.save_hist(st, ke, G, T0, meta); m.save_hist(st, ve, G, T0, meta); // the last window-1 positions stay as history
     }
-    {
-        const int tot = kvl + T0;
-        m.kv_len[s] = tot < m.window - 1 ? tot : m.window - 1;
+    for (int g = 0; g < G; g++) {
+        const int s = streams[g], tot = m.kv_len[s] + T0;
+        m.kv_len[s] = tot < W - 1 ? tot : W - 1;
         m.n_seen[s] += T0;
     }
-    // 4. final norm -> t1 [T0][H]
-    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(T0), dim3(256), 0, st, m.S->h.p, H, m.tf_norm.p, H, m.eps, m.S->t1.p, H);
-    // 5. upsample stages: x in t1
+    // 4. final norm -> t1 [R0][H]
+    hipLaunchKernelGGL(k_rmsnorm_rows, dim3(R0), dim3(256), 0, st, m.S->h.p, H, m.tf_norm.p, H, m.eps, m.S->t1.p, H);
+    // 5. upsample stages: x in t1 (plain rows; T = rows per stream)
     int T = T0;
     float* x = m.S->t1.p;
     for (int i = 0; i < m.n_up; i++) {
         auto& U = m.up[i];
         const int f = m.up_ratios[i];
         Ext& e = m.dw_ext[i];
-        m.run_conv(st, U.ct, x, H, T, e.cur(s), f * H); // [T][f*H] == [T*f][H]
+        m.load_hist(st, e, G, T * f, meta);
+        // transposed conv: GEMM row (g,t) writes f consecutive H-wide rows of segment g: [T][f*H] == [T*f][H]
+        m.run_conv(st, U.ct, m.plain(x), H, G * T, Impl::Loc{m.work(e) + (size_t)e.H * e.C, T, e.H}, f * H, H);
         T *= f;
-        hipLaunchKernelGGL(k_dwconv7, dim3((H + 255) / 256, T), dim3(256), 0, st, e.base(s), H, U.dw_w.p, U.dw_b.p, m.S->t2.p);
-        hipLaunchKernelGGL(k_layernorm_rows, dim3(T), dim3(256), 0, st, m.S->t2.p, H, U.ln_w.p, U.ln_b.p, H, 1e-6f, m.S->t2.p, H);
-        float* m1 = m.S->t1.p; // [T][4H]
-        m.run_conv(st, U.pw1, m.S->t2.p, H, T, m1, 4 * H, EPI_GELU);
+        hipLaunchKernelGGL(k_dwconv7, dim3((H + 255) / 256, G * T), dim3(256), 0, st, m.work(e), H, U.dw_w.p, U.dw_b.p, m.S->t2.p, m.base_map(e, T));
+        hipLaunchKernelGGL(k_layernorm_rows, dim3(G * T), dim3(256), 0, st, m.S->t2.p, H, U.ln_w.p, U.ln_b.p, H, 1e-6f, m.S->t2.p, H);
+        float* m1 = m.S->t1.p; // [G*T][4H]
+        m.run_conv(st, U.pw1, m.plain(m.S->t2.p), H, G * T, m.plain(m1), 4 * H, 4 * H, EPI_GELU);
         // y_new = y + gamma * (pw2(m1) + b): write into t2 (y lives in the ext buffer)
-        m.run_conv(st, U.pw2, m1, 4 * H, T, m.S->t2.p, H, EPI_RES_SCALE, e.cur(s), H, U.gamma.p);
-        m.shift(st, e, s, T);
+        m.run_conv(st, U.pw2, m.plain(m1), 4 * H, G * T, m.plain(m.S->t2.p), H, H, EPI_RES_SCALE, m.ext_cur(e, T), H, U.gamma.p);
+        m.save_hist(st, e, G, T, meta);
         // next stage input must not alias its own output buffers: move to t1
-        hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, m.S->t2.p, m.S->t1.p, (size_t)T * H);
+        m.copy_rows(st, m.S->t2.p, m.S->t1.p, G * T, H, plain_map());
         x = m.S->t1.p;
     }
     // 6. conv_in
-    hipLaunchKernelGGL(k_copy_rows, dim3((unsigned)(((size_t)T * H + 255) / 256)), dim3(256), 0, st, x, m.convin_ext.cur(s), (size_t)T * H);
-    m.run_conv(st, m.conv_in, m.convin_ext.base(s), H, T, m.S->t1.p, m.dec_dim);
-    m.shift(st, m.convin_ext, s, T);
-    float* d = m.S->t1.p; // [T][ch]
+    m.load_hist(st, m.convin_ext, G, T, meta);
+    m.copy_rows(st, x, m.work(m.convin_ext), G * T, H, m.cur_map(m.convin_ext, T));
+    m.run_conv(st, m.conv_in, m.ext_base(m.convin_ext, T), H, G * T, m.plain(m.S->t1.p), m.dec_dim, m.dec_dim);
+    m.save_hist(st, m.convin_ext, G, T, meta);
+    float* d = m.S->t1.p; // [G*T][ch]
     // 7. decoder blocks
     for (int b = 0; b < m.n_dec; b++) {
         auto& B = m.blk[b];
         Ext& ce = m.ct_ext[b];
-        m.snake(st, B.snake, d, ce.cur(s), T);
-        float* y = (d == m.S->t1.p) ? m.S->t2.p : m.S->t1.p; // [T*r][co]
-        m.run_conv(st, B.ct, ce.base(s), B.cin, T, y, B.rate * B.cout);
-        m.shift(st, ce, s, T);
+        m.load_hist(st, ce, G, T, meta);
+        m.snake(st, B.snake, d, m.work(ce), G * T, m.cur_map(ce, T));
+        float* y = (d == m.S->t1.p) ? m.S->t2.p : m.S->t1.p; // [G*T*r][co]
+        m.run_conv(st, B.ct, m.ext_base(ce, T), B.cin, G * T, m.plain(y), B.rate * B.cout, B.cout);
+        m.save_hist(st, ce, G, T, meta);
         T *= B.rate;
         for (int u = 0; u < 3; u++) {
             Ext& re = m.ru_ext[b][u];
             auto& R = B.ru[u];
-            m.snake(st, R.s1, y, re.cur(s), T);
-            float* c1o = d; // the block input buffer is free now: reuse as scratch [T][co]
-            m.run_conv(st, R.c1, re.base(s), B.cout, T, c1o, B.cout, EPI_SNAKE, nullptr, 0, nullptr, &R.s2); // conv1 + snake2 fused
-            m.shift(st, re, s, T);
-            m.run_conv(st, R.c2, c1o, B.cout, T, y, B.cout, EPI_RES, y, B.cout);
+            m.load_hist(st, re, G, T, meta);
+            m.snake(st, R.s1, y, m.work(re), G * T, m.cur_map(re, T));
+            float* c1o = d; // the block input buffer is free now: reuse as scratch [G*T][co]
+            m.run_conv(st, R.c1, m.ext_base(re, T), B.cout, G * T, m.plain(c1o), B.cout, B.cout, EPI_SNAKE, Impl::Loc{nullptr, SEG_NONE, 0}, 0, nullptr, &R.s2); // conv1 + snake2 fused
+            m.save_hist(st, re, G, T, meta);
+            m.run_conv(st, R.c2, m.plain(c1o), B.cout, G * T, m.plain(y), B.cout, B.cout, EPI_RES, m.plain(y), B.cout);
         }
         d = y;
     }
     // 8. output conv
-    m.snake(st, m.snake_out, d, m.out_ext.cur(s), T);
-    hipLaunchKernelGGL(k_conv_out, dim3((T + 255) / 256), dim3(256), 0, st, m.out_ext.base(s), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, T);
-    m.shift(st, m.out_ext, s, T);
-    Q3_HIP(hipMemcpyAsync(pcm, m.S->pcm.p, (size_t)T * 4, hipMemcpyDeviceToHost, st));
+    m.load_hist(st, m.out_ext, G, T, meta);
+    m.snake(st, m.snake_out, d, m.work(m.out_ext), G * T, m.cur_map(m.out_ext, T));
+    hipLaunchKernelGGL(k_conv_out, dim3((G * T + 255) / 256), dim3(256), 0, st, m.work(m.out_ext), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T,
+                       m.base_map(m.out_ext, T));
+    m.save_hist(st, m.out_ext, G, T, meta);
+    for (int g = 0; g < G; g++) Q3_HIP(hipMemcpyAsync(pcm[g], m.S->pcm.p + (size_t)g * T, (size_t)T * 4, hipMemcpyDeviceToHost, st));
     return T;
 }
 

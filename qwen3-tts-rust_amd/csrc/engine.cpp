@@ -103,8 +103,9 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     upload_slot_state();
     if (p.load_codec) {
         // codec streams outnumber the slots: a retired sequence's last chunks still drain while its slot is already reused
-        const int n_cs = B + std::min(B, 16), n_lanes = std::min(B, 8);
-        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes));
+        // up to 16 streams share one decode pass; two lanes (HIP streams + scratch) let consecutive groups overlap
+        const int n_cs = B + std::min(B, 16), gmax = std::min(B, 16), n_lanes = B > 1 ? 2 : 1;
+        codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes, gmax));
         st2_.resize(n_lanes);
         for (auto& s2 : st2_) Q3_HIP(hipStreamCreate(&s2));
         slot_cap_ = (size_t)p.max_steps * codec_->samples_per_frame();
@@ -290,31 +291,66 @@ void Engine::prefill(const std::vector<Req*>& batch, bool sampled) {
 void Engine::decoder_main() {
     try {
         Q3_HIP(hipSetDevice(dev_)); // HIP's current device is per thread
-        const int spf = codec_->samples_per_frame();
+        const int spf = codec_->samples_per_frame(), gmax = codec_->max_group(), n_lanes = (int)st2_.size();
+        std::map<Req*, std::pair<int, hipEvent_t>> last;            // request -> (lane, event after its latest chunk)
+        int next_lane = 0;
         for (;;) {
-            DecTask t;
+            // take the oldest task; if it is a chunk, add the first pending chunk of other requests with the same frame count:
+            // one decode pass then serves the whole group (weights streamed once, one set of launches)
+            std::vector<DecTask> grp;
             {
                 std::unique_lock<std::mutex> lk(dmu_);
                 dcv_.wait(lk, [&] { return dec_stop_ || !dq_.empty(); });
                 if (dq_.empty()) return;
-                t = std::move(dq_.front());
+                grp.push_back(std::move(dq_.front()));
                 dq_.pop_front();
+                if (!grp[0].fence && gmax > 1) {
+                    const size_t nc = grp[0].codes.size();
+                    std::vector<Req*> seen{grp[0].r};
+                    for (auto it = dq_.begin(); it != dq_.end() && (int)grp.size() < gmax;) {
+                        const bool dup = std::find(seen.begin(), seen.end(), it->r) != seen.end();
+                        if (!dup) seen.push_back(it->r);
+                        if (!dup && !it->fence && it->codes.size() == nc) { grp.push_back(std::move(*it)); it = dq_.erase(it); }
+                        else ++it;
+                    }
+                }
             }
-            Req* r = t.r;
-            const int lane = r->cs % (int)st2_.size();
-            if (!t.fence) {
-                const int nf = (int)t.codes.size() / 16;
-                Q3_CHECK(r->pcm_enq + (size_t)nf * spf <= slot_cap_, "pcm staging overflow");
-                // engine.rs:520: decode the chunk -- enqueued on a codec stream, overlapping the next AR frames
-                const int got = codec_->decode_async(st2_[lane], r->cs, t.codes.data(), nf, t.is_final, pcm_pinned_ + (size_t)r->cs * slot_cap_ + r->pcm_enq, lane);
-                r->pcm_enq += (size_t)std::max(got, 0);
+            const int G = (int)grp.size();
+            int lane = next_lane;
+            { auto it = last.find(grp[0].r); if (G == 1 && it != last.end()) lane = it->second.first; else next_lane = (next_lane + 1) % n_lanes; }
+            for (auto& t : grp) { // a request's chunks must run in order even when consecutive groups use different lanes
+                auto it = last.find(t.r);
+                if (it != last.end() && it->second.first != lane) Q3_HIP(hipStreamWaitEvent(st2_[lane], it->second.second, 0));
             }
-            hipEvent_t ev;
-            Q3_HIP(hipEventCreate(&ev));
-            Q3_HIP(hipEventRecord(ev, st2_[lane])); // first one = the reference's first stream_tx.send (:522-523)
-            {
+            if (!grp[0].fence) {
+                const int nf = (int)grp[0].codes.size() / 16;
+                std::vector<int> streams(G);
+                std::vector<float*> dst(G);
+                std::vector<int64_t> codes((size_t)G * nf * 16);
+                for (int g = 0; g < G; g++) {
+                    Req* r = grp[g].r;
+                    Q3_CHECK(r->pcm_enq + (size_t)nf * spf <= slot_cap_, "pcm staging overflow");
+                    streams[g] = r->cs; dst[g] = pcm_pinned_ + (size_t)r->cs * slot_cap_ + r->pcm_enq;
+                    std::copy(grp[g].codes.begin(), grp[g].codes.end(), codes.begin() + (size_t)g * nf * 16);
+                }
+                // engine.rs:520: decode the chunk(s) -- enqueued on a codec stream, overlapping the next AR frames
+                const int got = codec_->decode_group_async(st2_[lane], G, streams.data(), codes.data(), nf, dst.data(), lane);
+                for (int g = 0; g < G; g++) grp[g].r->pcm_enq += (size_t)std::max(got, 0);
+            }
+            for (auto& t : grp) {
+                hipEvent_t ev;
+                Q3_HIP(hipEventCreate(&ev));
+                Q3_HIP(hipEventRecord(ev, st2_[lane])); // first one = the reference's first stream_tx.send (:522-523)
+                if (t.fence) { auto it = last.find(t.r); if (it != last.end()) { (void)hipEventDestroy(it->second.second); last.erase(it); } }
+                else {
+                    hipEvent_t ord;
+                    auto it = last.find(t.r);
+                    if (it == last.end()) { Q3_HIP(hipEventCreateWithFlags(&ord, hipEventDisableTiming)); last[t.r] = {lane, ord}; }
+                    else { ord = it->second.second; it->second.first = lane; }
+                    Q3_HIP(hipEventRecord(ord, st2_[lane]));
+                }
                 std::lock_guard<std::mutex> lk(dmu_);
-                comp_.push_back(Completion{r, ev, r->pcm_enq, t.fence});
+                comp_.push_back(Completion{t.r, ev, t.r->pcm_enq, t.fence});
                 if (!t.fence) stats.codec_calls++;
             }
             dcv_.notify_all();
