@@ -40,6 +40,8 @@ struct KvCache {           // paged f16 KV cache (pages of 64 positions)
 };
 
 // out[(sseg*ntok + tok)*out_stride + r] = super-segment partial of row (row0+r) . x[tok]      (spec S3)
+// batched steps: gate/up GEMM on the matrix cores with the SwiGLU + quantisation epilogue; false = shape not supported (caller falls back)
+bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok);
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
                     float* out, int out_stride, int ntok, int lpr_hint = 0);
 

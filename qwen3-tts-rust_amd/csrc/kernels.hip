@@ -81,8 +81,15 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
 
 __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                               float* __restrict__ out, int out_stride, int ntok);
+template <bool GU>
 __global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                               float* __restrict__ out, int out_stride, int ntok);
+                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+// token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
+static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
+    const int ntiles = (ntok + 31) / 32;
+    int z = (256 + rowgroups * nsseg - 1) / (rowgroups * nsseg);
+    return z < 1 ? 1 : (z > ntiles ? ntiles : z);
+}
 
 // =====================================================================================================
 // Mixed-type form (Q5_K_M files: Q5_K + Q6_K + Q8_0 rows in one fused matrix).  Same wave mapping and the same
@@ -221,8 +228,9 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     }
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
-        hipLaunchKernelGGL(k_gemm_q8_mfma, dim3((nrows + 31) / 32, nsseg, (ntok + 31) / 32), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                           out_stride, ntok);
+        const int rgs = (nrows + 31) / 32;
+        hipLaunchKernelGGL((k_gemm_q8_mfma<false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                           out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
         return;
     }
     if (ntok > 8 && !lpr_hint) {
@@ -243,6 +251,16 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (lpr == 2) gemv_launch_mt<2>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
     else if (lpr == 4) gemv_launch_mt<4>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
     else gemv_launch_mt<8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+}
+
+// gate/up GEMM + SwiGLU + int8 quantisation for batched steps (ntok >= 16, pure Q8_0, K = 1024 or 2048)
+bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok) {
+    if (wgu.rg_type || ntok < 16 || (wgu.K != 1024 && wgu.K != 2048) || (ff & 31)) return false;
+    const int rgs = ff / 32, ntiles = (ntok + 31) / 32;
+    int z = mfma_ztiles(rgs, 1, ntok);
+    if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
+    hipLaunchKernelGGL((k_gemm_q8_mfma<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    return true;
 }
 
 // =====================================================================================================
@@ -328,65 +346,106 @@ __global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrow
 // =====================================================================================================
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
+// The workgroup keeps its weight tile (32 rows x one super-segment) in registers and loops over 32-token tiles
+// (tile = blockIdx.z, += gridDim.z), so weights are streamed once per launch when gridDim.z = 1.
+// GU = gate/up form for K <= 2048: pass 0 runs the 32 gate rows over the workgroup's tiles and parks the sums in LDS, pass 1
+// runs the 32 matching up rows and finishes with SwiGLU + int8 quantisation of the 32-row block (spec S8, S2); the f32
+// gate/up matrix never reaches memory.  A GU workgroup handles at most 4 token tiles (launcher picks gridDim.z accordingly).
+template <bool GU>
 __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
-                                                      int ntok) {
+                                                      int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ float red[8][32][33];
+    __shared__ __attribute__((aligned(16))) uint16_t sc_s[8][2][8][16]; // [wave][lane half][block][accumulator reg]: f16 activation scales
+    __shared__ float gate_s[GU ? 4 : 1][GU ? 1024 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
     const int nseg = w.K >> 8, nb = w.K >> 5;
     const int sseg = blockIdx.y, seg = sseg * 8 + wave;
-    const int tok0 = blockIdx.z * 32;
     int nsg = nseg - sseg * 8;
     if (nsg > 8) nsg = 8;
-    if (seg < nseg) {
-        int row = row0 + blockIdx.x * 32 + r;
-        if (row > w.Npad - 1) row = w.Npad - 1;
-        const int rg = row >> 5, r32 = row & 31;
-        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-        i32x4v wv[8], av[8];
+    const bool active = seg < nseg;
+    const int ntiles = (ntok + 31) >> 5;
+    constexpr int NM = GU ? 2 : 1;
+#pragma unroll 1
+    for (int q = 0; q < NM; q++) {
+        i32x4v wv[8];
+        uint4 dwv = make_uint4(0, 0, 0, 0);
+        if (active) {
+            int row = row0 + blockIdx.x * 32 + r + q * ff;
+            if (row > w.Npad - 1) row = w.Npad - 1;
+            const int rg = row >> 5, r32 = row & 31;
+            const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
 #pragma unroll
-        for (int i = 0; i < 8; i++) wv[i] = *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
-        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
-        int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
-        if (atok > ntok - 1) atok = ntok - 1;
-        const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
-#pragma unroll
-        for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + i * 32);
-        // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
-        uint4 dxv[16];
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            int t = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
-            if (t > ntok - 1) t = ntok - 1;
-            dxv[g] = *reinterpret_cast<const uint4*>(xd + (size_t)t * nb + seg * 8);
+            for (int i = 0; i < 8; i++) wv[i] = *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
+            dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
         }
-        float acc[16];
-#pragma unroll
-        for (int g = 0; g < 16; g++) acc[g] = 0.0f;
-#pragma unroll
-        for (int i = 0; i < 8; i++) {
-            i32x16 c;
-#pragma unroll
-            for (int g = 0; g < 16; g++) c[g] = 0;
-            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
-            const float dwf = h2f(half_of(dwv, i));
-#pragma unroll
-            for (int g = 0; g < 16; g++) {
-                const float sc = dwf * h2f(half_of(dxv[g], i));
-                acc[g] = q3_fmaf((float)c[g], sc, acc[g]);
+        int lt = 0;
+#pragma unroll 1
+        for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z, lt++) {
+            const int tok0 = tt * 32;
+            if (active) { // stage this wave's activation scales: token (lane & 31), blocks 4*(lane >> 5) .. +3
+                int t = tok0 + r;
+                if (t > ntok - 1) t = ntok - 1;
+                const uint2 v = *reinterpret_cast<const uint2*>(xd + (size_t)t * nb + seg * 8 + 4 * half);
+                const int th = (r >> 2) & 1, tg = (r & 3) + 4 * (r >> 3); // token r sits in C row (reg tg, lane half th)
+                sc_s[wave][th][4 * half + 0][tg] = (uint16_t)(v.x & 0xFFFFu); sc_s[wave][th][4 * half + 1][tg] = (uint16_t)(v.x >> 16);
+                sc_s[wave][th][4 * half + 2][tg] = (uint16_t)(v.y & 0xFFFFu); sc_s[wave][th][4 * half + 3][tg] = (uint16_t)(v.y >> 16);
             }
-        }
+            __syncthreads();
+            if (active) {
+                i32x4v av[8];
+                int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
+                if (atok > ntok - 1) atok = ntok - 1;
+                const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
 #pragma unroll
-        for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
-    }
-    __syncthreads();
-    for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) {
-        const int m = t >> 5, rr = t & 31;
-        float S = red[0][m][rr];
-        for (int s = 1; s < nsg; s++) S = S + red[s][m][rr];
-        const int orow = blockIdx.x * 32 + rr, tok = tok0 + m;
-        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+                for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + i * 32);
+                // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
+                float acc[16];
+#pragma unroll
+                for (int g = 0; g < 16; g++) acc[g] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    i32x16 c;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) c[g] = 0;
+                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
+                    const float dwf = h2f(half_of(dwv, i));
+                    const uint4 s0 = *reinterpret_cast<const uint4*>(&sc_s[wave][half][i][0]);
+                    const uint4 s1 = *reinterpret_cast<const uint4*>(&sc_s[wave][half][i][8]);
+#pragma unroll
+                    for (int g = 0; g < 16; g++) {
+                        const float sc = dwf * h2f(half_of(g < 8 ? s0 : s1, g & 7));
+                        acc[g] = q3_fmaf((float)c[g], sc, acc[g]);
+                    }
+                }
+#pragma unroll
+                for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
+            }
+            __syncthreads();
+            for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
+                const int m = t >> 5, rr = t & 31, tok = tok0 + m;
+                float S = red[0][m][rr];
+                for (int s2 = 1; s2 < nsg; s2++) S = S + red[s2][m][rr];
+                if (!GU) {
+                    const int orow = blockIdx.x * 32 + rr;
+                    if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+                } else if (q == 0) gate_s[lt][t] = S; // read back by the same thread in pass 1
+                else {
+                    const float y = q3_swiglu(gate_s[lt][t], S);
+                    float amax = q3_fabsf(y);
+#pragma unroll
+                    for (int s2 = 16; s2 >= 1; s2 >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s2));
+                    const float dd = amax / 127.0f;
+                    const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+                    if (tok < ntok) {
+                        aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
+                        if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+                    }
+                }
+            }
+            __syncthreads(); // red / sc_s are rewritten by the next tile
+        }
     }
 }
 

@@ -801,9 +801,35 @@ __global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x
         out[(size_t)tok * out_stride + o] = sum;
     }
 }
+// Many tokens: thread = one (token, output) chain; the 16 outputs of a workgroup read the weight slab straight from global (the 16
+// token groups of the workgroup hit the same 64-byte line), activations of 16 tokens are staged in LDS as [i][token].
+__global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x, int x_stride, const float* __restrict__ Wblk,
+                                                    const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
+                                                    int out_stride, int ntok) {
+    extern __shared__ __attribute__((aligned(16))) float xs[]; // [n_in][16]
+    const int ob = blockIdx.x, t0 = blockIdx.y * 16, tid = threadIdx.x;
+    const int o16 = tid & 15, tl = tid >> 4;
+    for (int e = tid; e < n_in * 16; e += 256) {
+        const int t = e / n_in, i = e % n_in; // coalesced global reads along i
+        xs[i * 16 + t] = (t0 + t < ntok) ? x[(size_t)(t0 + t) * x_stride + i] : 0.0f;
+    }
+    __syncthreads();
+    const float* wp = Wblk + (size_t)ob * n_in * 16 + o16;
+    const int o = ob * 16 + o16;
+    float sum = b[o];
+#pragma unroll 16
+    for (int i = 0; i < n_in; i++) { const float t = xs[i * 16 + tl] * wp[(size_t)i * 16]; sum = sum + t; }
+    if (t0 + tl < ntok) out[(size_t)(t0 + tl) * out_stride + o] = sum;
+}
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
                         float* out, int out_stride, int ntok) {
-    static bool attr_set = false;
+    static bool attr_set = false, attr_mt = false;
+    if (ntok > 2) {
+        if (!attr_mt) { (void)hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_mt = true; }
+        hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), (size_t)n_in * 16 * sizeof(float), st, x, x_stride, Wblk, b,
+                           n_in, n_out, out, out_stride, ntok);
+        return;
+    }
     const size_t lds = (size_t)n_in * 17 * sizeof(float);
     if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
     hipLaunchKernelGGL(k_project_blk, dim3(n_out / 16, ntok), dim3(256), lds, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride);

@@ -322,16 +322,29 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p;
         norm(a);
         gemv(st, L.wqkv, 0, dq + 2 * dkv, xq_.p, xd_.p, qkv_.p, dq + 2 * dkv, ntok);
-        launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
-                              rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
-        launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
+        if (fused && !same_seq_) // batched decode step: every token belongs to another sequence -> one fused attention launch
+            launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                                   n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
+        else {
+            launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
+                                  rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
+            launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
+        }
         gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
         NormArgs b{};
         b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.h_out = h_.p;
         b.g = L.ffn_norm; b.eps = hp_.eps; b.d = d; b.xq = xq_.p; b.xd = xd_.p;
         norm(b);
-        gemv(st, L.wgu, 0, 2 * ff, xq_.p, xd_.p, gu_.p, 2 * ff, ntok);
-        launch_swiglu_quant(st, gu_.p, ff, fq_.p, fd_.p, ntok);
+        bool gu_done = false;
+        if (fused) {
+            if (timer) timer->begin(st);
+            gu_done = launch_gateup_mfma(st, L.wgu, ff, xq_.p, xd_.p, fq_.p, fd_.p, ntok);
+            if (timer && gu_done) timer->end(st, (double)L.wgu.bytes()); // an unmatched begin() is simply re-recorded by the next one
+        }
+        if (!gu_done) {
+            gemv(st, L.wgu, 0, 2 * ff, xq_.p, xd_.p, gu_.p, 2 * ff, ntok);
+            launch_swiglu_quant(st, gu_.p, ff, fq_.p, fd_.p, ntok);
+        }
         gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
     }
     NormArgs f{};

@@ -284,6 +284,24 @@ def test_scheduler_driver_thread_and_voices(tiny_engines, vivian):
         assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
 
 
+def test_engine_wide_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
+    """18 concurrent sequences: the batched-step kernels (int8-MFMA GEMM with token-tile loop, gate/up GEMM with the SwiGLU+quant
+    epilogue, fused attention for many sequences, multi-token projection) and 16-stream codec groups, against oracle singles."""
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=18, max_steps=16, load_codec=True)
+    oe = oracle.Engine(os.path.join(tiny_model, "gguf_q8_0"), os.path.join(tiny_model, "onnx", "q3tts_codec.gguf"), 4)
+    rng = np.random.default_rng(31)
+    prompts = [ge.assets.build_core(rng.integers(0, 4000, 3 + (5 * i) % 23).astype(np.int32), lang_id=2055, spk_emb=vivian) for i in range(18)]
+    steps = [6 + (i % 4) for i in range(18)]
+    temps = [0.0 if i % 5 else 0.9 for i in range(18)]
+    res = ge.generate_batch(prompts, max_steps=steps, temperature=temps, top_k=20, top_p=0.9, seed=[7 + i for i in range(18)], mask_eos=True,
+                            want_pcm=True)
+    for i, (p, r) in enumerate(zip(prompts, res)):
+        oc, opcm = oe.generate(p, max_steps=steps[i], temperature=temps[i], top_k=20, top_p=0.9, seed=7 + i, mask_eos=True, want_pcm=True)
+        assert np.array_equal(oc, r["codes"]), i
+        assert r["pcm"].size == opcm.size and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL, i
+    ge.close(); oe.close()
+
+
 def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     """BASELINE.json configs[0] quantisation (Q5_K_M = Q5_K + Q6_K rows) on the GPU: K-quant rows are expanded to int8 planes at
     load (exact) and run through the mixed-type GEMV; tokens must equal the oracle's Q5_K/Q6_K block arithmetic bit for bit."""
