@@ -8,6 +8,7 @@
 // 16-B-per-lane coalesced weight streams (1 KiB per wave instruction), all of a wave's weight loads issued
 // before first use, wave-shuffle reductions, and >=256 workgroups per launch.  No MFMA here on purpose.
 #include "kernels.h"
+#include <cstdlib>
 #include "../../include/q3tts_spec.h"
 #include "kdev.h"
 
@@ -87,7 +88,8 @@ __global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __res
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
     const int ntiles = (ntok + 31) / 32;
-    int z = (256 + rowgroups * nsseg - 1) / (rowgroups * nsseg);
+    static const int target = [] { const char* e = std::getenv("Q3_MFMA_WGS"); return e ? atoi(e) : 512; }(); // measured on MI355X at 64 tokens: 128 -> 6.74, 256 -> 6.16, 512 -> 6.13 ms/step
+    int z = (target + rowgroups * nsseg - 1) / (rowgroups * nsseg);
     return z < 1 ? 1 : (z > ntiles ? ntiles : z);
 }
 
