@@ -82,7 +82,10 @@ def main():
     ap.add_argument("--model-dir", default=os.environ.get("Q3_BENCH_MODEL", "/tmp/q3tts_synth_full"))
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-codec", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="lock-stepped utterances per GPU (1 = config C2, 64 = config C3)")
+    ap.add_argument("--batch", type=int, default=1, help="sequence slots per GPU (1 = config C2, 64 = config C3)")
+    ap.add_argument("--requests", type=int, default=0, help="utterances per GPU (default = --batch); more than --batch queue up and are "
+                                                            "admitted by the continuous-batching scheduler as slots retire")
+    ap.add_argument("--ragged", action="store_true", help="utterance lengths 50..100 %% of 4*steps frames (slots retire at different times)")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -130,10 +133,19 @@ def main():
     prompt = build_prompt(eng.assets, spk_emb)
     log("engine up, prompt rows %d" % prompt.shape[0])
 
-    prompts = [prompt] if args.batch == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(args.batch)]
+    n_req = max(args.requests, args.batch)
+    prompts = [prompt] if n_req == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(n_req)]
+    last_run = {}
 
     def run(steps, pcm):
-        return eng.generate_batch(prompts, max_steps=4 * steps, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)[0]
+        ms = [4 * steps] * n_req
+        if args.ragged:
+            ms = [max(1, int(4 * steps * (0.5 + 0.5 * ((i * 7) % 11) / 10.0))) for i in range(n_req)]
+        res = eng.generate_batch(prompts, max_steps=ms, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)
+        last_run["frames"] = sum(r["codes"].shape[0] for r in res)
+        last_run["first_chunk"] = [r["first_chunk_ms"] for r in res]
+        assert all(r["codes"].shape[0] == m for r, m in zip(res, ms)), "EOS-masked runs must emit exactly max_steps frames"
+        return res[0]
 
     if args.warmup > 0:
         run(args.warmup, have_codec)
@@ -155,16 +167,19 @@ def main():
     st = eng.stats()
     log("timed region done: %.3f s" % elapsed)
     n_frames = res["codes"].shape[0]
-    assert n_frames == 4 * args.steps, "EOS-masked run must emit exactly 4*steps frames"
-    audio_s = n_frames * FRAME_SEC * args.batch
+    audio_s = last_run["frames"] * FRAME_SEC
+    timed_first_chunk = list(last_run["first_chunk"])
 
     out = None
     if rank == 0:
         # first-chunk latency (submit -> first PCM chunk available, engine.rs:522-523 analogue): p50 over short utterances
         lat = []
-        for _ in range(5):
-            r = run(2, have_codec)
-            lat.append(r["first_chunk_ms"] if have_codec else r["prefill_ms"] + (r["total_ms"] - r["prefill_ms"]) / 2.0)
+        if n_req == 1:
+            for _ in range(5):
+                r = run(2, have_codec)
+                lat.append(r["first_chunk_ms"] if have_codec else r["prefill_ms"] + (r["total_ms"] - r["prefill_ms"]) / 2.0)
+        else:  # many utterances: the timed run's own per-request latencies (includes queueing behind the batched prefill)
+            lat = [v for v in timed_first_chunk if v > 0] or [0.0]
         log("latency runs done")
         # instrumented leg: same K steps, eager launches with a HIP-event pair around every k_gemv_q8 launch
         eng.reset_stats()
@@ -172,19 +187,20 @@ def main():
         run(args.steps, False)
         eng.set_instrument(False)
         si = eng.stats()
-        mean_ctx = prompt.shape[0] + n_frames / 2.0
+        mean_ctx = prompt.shape[0] + 4 * args.steps / 2.0
         step_bytes = eng.bytes_per_step(args.batch, mean_ctx)
         fam_bytes, fam_ms, fam_n = si["gemv_bytes"] + si["gu_bytes"], si["gemv_ms"] + si["gu_ms"], si["gemv_launches"] + si["gu_launches"]
         gemv_gbs = fam_bytes / (fam_ms * 1e-3) / 1e9 if fam_ms > 0 else 0.0
         gu_gbs = si["gu_bytes"] / (si["gu_ms"] * 1e-3) / 1e9 if si["gu_ms"] > 0 else 0.0
-        frame_ms = st["frame_loop_ms"] / max(st["frames"] / args.batch, 1)   # one batched step advances every sequence by a frame
+        frame_ms = st["frame_loop_ms"] / max(st["graph_frames"], 1)   # one graph replay advances every active slot by a frame
         out = {
             "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
             "value": world * audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "i8", "data": "synthetic",
-            "config": {"workload": ("C2 single utterance per GPU" if args.batch == 1 else "C3-style %d lock-stepped utterances per GPU" % args.batch) + ", Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
-                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": args.batch,
+            "config": {"workload": ("C2 single utterance per GPU" if n_req == 1 else "C3-style %d utterances through %d slots per GPU (continuous batching)" % (n_req, args.batch)) + ", Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
+                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": args.batch, "requests_per_gpu": n_req, "ragged": bool(args.ragged),
+                       "mean_graph_width": st["slot_frames"] / max(st["graph_frames"], 1),
                        "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
             "rtf": elapsed / audio_s,
             "first_chunk_ms_p50": statistics.median(lat),

@@ -81,6 +81,7 @@ typedef struct q3tts_stats {
     double talker_weight_bytes, predictor_weight_bytes, kv_bytes_per_token;
     double gu_ms; int64_t gu_launches; double gu_bytes;       /* talker gate/up kernel alone (instrumented leg) */
     int64_t sched_steps; double slot_frames;                  /* scheduler: frame groups launched, sum of graph width x frames */
+    int64_t graph_frames;                                     /* frame-graph replays (each advances every active slot by one frame) */
 } q3tts_stats;
 int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* out);
 void q3tts_engine_reset_stats(q3tts_engine* e);

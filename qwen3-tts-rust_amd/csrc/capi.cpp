@@ -162,7 +162,7 @@ int q3tts_engine_stats(q3tts_engine* e, q3tts_stats* o) {
     o->frame_loop_ms = s.frame_loop_ms; o->frames = s.frames; o->prefill_ms = s.prefill_ms; o->gemv_ms = s.gemv_ms;
     o->gemv_launches = s.gemv_launches; o->gemv_bytes = s.gemv_bytes; o->codec_ms = s.codec_ms; o->codec_calls = s.codec_calls;
     o->gu_ms = s.gu_ms; o->gu_launches = s.gu_launches; o->gu_bytes = s.gu_bytes;
-    o->sched_steps = s.steps; o->slot_frames = s.slot_frames;
+    o->sched_steps = s.steps; o->slot_frames = s.slot_frames; o->graph_frames = s.graph_frames;
     o->talker_weight_bytes = (double)e->e->talker().weight_bytes(); o->predictor_weight_bytes = (double)e->e->predictor().weight_bytes();
     const auto& hp = e->e->talker().hp();
     o->kv_bytes_per_token = (double)hp.n_layer * 2 * hp.n_kv * 128 * 2;

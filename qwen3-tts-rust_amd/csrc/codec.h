@@ -17,6 +17,7 @@ public:
     ~CodecDecoder();
     int samples_per_frame() const;
     void reset(int stream); // AudioDecoder::create_state (onnx.rs:338-340, 474-495)
+    void reset_async(hipStream_t st, int stream); // same, ordered on `st` (call from the thread that issues the decodes)
     // codes: host [n_frames][16] (already clamped to [0,2047], engine.rs:515-519); pcm: host, n_frames*spf floats
     int decode(hipStream_t st, int stream, const int64_t* codes, int n_frames, bool is_last, float* pcm);
     // same, but returns right after enqueueing: pcm_pinned must be hipHostMalloc'd and stay valid until `st` is synchronised

@@ -650,6 +650,13 @@ void CodecDecoder::reset(int s) {
     m.kv_len[s] = 0; m.n_seen[s] = 0;
 }
 
+void CodecDecoder::reset_async(hipStream_t st, int s) {
+    Impl& m = *impl_;
+    Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
+    for (Ext* e : m.all_ext) if (e->H) Q3_HIP(hipMemsetAsync(e->hist.p + (size_t)s * e->H * e->C, 0, (size_t)e->H * e->C * 4, st));
+    m.kv_len[s] = 0; m.n_seen[s] = 0;
+}
+
 int CodecDecoder::decode(hipStream_t st, int s, const int64_t* codes, int n_frames, bool is_last, float* pcm) {
     const int T = decode_async(st, s, codes, n_frames, is_last, pcm, 0);
     Q3_HIP(hipStreamSynchronize(st));

@@ -25,7 +25,7 @@ static double now_ms() {
 Engine::Engine(const EngineParams& p) : p_(p) {
     Q3_CHECK(p.max_batch >= 1 && p.max_batch <= 512, "max_batch out of range");
     Q3_HIP(hipGetDevice(&dev_));
-    Q3_HIP(hipStreamCreate(&st_));
+    Q3_HIP(hipStreamCreateWithFlags(&st_, hipStreamNonBlocking));
     const std::string dir = p.model_dir + "/" + quant_dir(p.quant);
     assets_.reset(new HostAssets(dir + "/qwen3_assets.gguf"));
     const int B = p.max_batch;
@@ -100,6 +100,9 @@ Engine::Engine(const EngineParams& p) : p_(p) {
         std::vector<q3_u64> k0((size_t)16 * B, pack_key(-INFINITY, 0)), n0(B, pack_key(-INFINITY, 0));
         d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
     }
+    arena_cap_ = (size_t)talker_->max_tok() * Q3_EMBD * 4 + (size_t)B * 4096 + ((size_t)1 << 20);
+    Q3_HIP(hipHostMalloc((void**)&arena_, arena_cap_));
+    Q3_HIP(hipDeviceSynchronize()); // memsets / table kernels above ran on other streams than st_
     upload_slot_state();
     if (p.load_codec) {
         // codec streams outnumber the slots: a retired sequence's last chunks still drain while its slot is already reused
@@ -107,12 +110,33 @@ Engine::Engine(const EngineParams& p) : p_(p) {
         const int n_cs = B + std::min(B, 16), gmax = std::min(B, 16), n_lanes = B > 1 ? 2 : 1;
         codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes, gmax));
         st2_.resize(n_lanes);
-        for (auto& s2 : st2_) Q3_HIP(hipStreamCreate(&s2));
+        for (auto& s2 : st2_) Q3_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
         slot_cap_ = (size_t)p.max_steps * codec_->samples_per_frame();
         Q3_HIP(hipHostMalloc((void**)&pcm_pinned_, (size_t)n_cs * slot_cap_ * sizeof(float)));
         for (int c = n_cs - 1; c >= 0; c--) cs_free_.push_back(c);
     }
     Q3_HIP(hipStreamSynchronize(st_));
+    Q3_HIP(hipDeviceSynchronize());
+    arena_used_ = 0;
+}
+
+void* Engine::stage_alloc(size_t bytes) {
+    bytes = (bytes + 63) & ~(size_t)63;
+    Q3_CHECK(bytes <= arena_cap_, "staging request larger than the arena");
+    if (arena_used_ + bytes > arena_cap_) { Q3_HIP(hipStreamSynchronize(st_)); arena_used_ = 0; } // everything staged so far has been consumed
+    void* p = arena_ + arena_used_;
+    arena_used_ += bytes;
+    return p;
+}
+void Engine::h2d(void* dst, const void* src, size_t bytes) {
+    void* p = stage_alloc(bytes);
+    std::memcpy(p, src, bytes);
+    Q3_HIP(hipMemcpyAsync(dst, p, bytes, hipMemcpyHostToDevice, st_));
+}
+void* Engine::d2h_begin(const void* src, size_t bytes) {
+    void* p = stage_alloc(bytes);
+    Q3_HIP(hipMemcpyAsync(p, src, bytes, hipMemcpyDeviceToHost, st_));
+    return p;
 }
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -144,6 +168,7 @@ Engine::~Engine() {
         if (g.second->graph) (void)hipGraphDestroy(g.second->graph);
     }
     if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
+    if (arena_) (void)hipHostFree(arena_);
     for (auto s2 : st2_) (void)hipStreamDestroy(s2);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -234,9 +259,9 @@ void Engine::upload_slot_state() {
     for (int b = 0; b < W; b++) {
         if (!slot_req_.empty() && slot_req_[b]) { const int t = h_nprompt_[b] + h_nfr_[b]; tslot[b] = t; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = t; }
     }
-    d_maxframes_.upload(h_maxf_.data(), W); d_finished_.upload(h_fin_.data(), W); d_nframes_.upload(h_nfr_.data(), W);
-    d_tslot_.upload(tslot.data(), W); d_tpos_.upload(tpos.data(), (size_t)4 * W); d_maskeos_.upload(h_mask_.data(), W);
-    d_temp_.upload(h_temp_.data(), W); d_topk_.upload(h_topk_.data(), W); d_topp_.upload(h_topp_.data(), W);
+    h2d(d_maxframes_.p, h_maxf_.data(), (size_t)W * 4); h2d(d_finished_.p, h_fin_.data(), (size_t)W * 4); h2d(d_nframes_.p, h_nfr_.data(), (size_t)W * 4);
+    h2d(d_tslot_.p, tslot.data(), (size_t)W * 4); h2d(d_tpos_.p, tpos.data(), (size_t)16 * W); h2d(d_maskeos_.p, h_mask_.data(), (size_t)W * 4);
+    h2d(d_temp_.p, h_temp_.data(), (size_t)W * 4); h2d(d_topk_.p, h_topk_.data(), (size_t)W * 4); h2d(d_topp_.p, h_topp_.data(), (size_t)W * 4);
     slot_dirty_ = false;
 }
 
@@ -247,7 +272,6 @@ void Engine::prefill(const std::vector<Req*>& batch, bool sampled) {
     size_t total = 0;
     for (Req* r : batch) total += (size_t)r->r.n_prompt;
     const int chunk = talker_->max_tok();
-    std::vector<float> stage((size_t)chunk * Q3_EMBD);
     std::vector<int32_t> seq(chunk), slot(chunk), pos((size_t)4 * chunk);
     size_t bi = 0; int t = 0; // cursor over (request, token)
     size_t done = 0;
@@ -255,18 +279,17 @@ void Engine::prefill(const std::vector<Req*>& batch, bool sampled) {
     while (done < total) {
         int n = 0;
         std::vector<std::pair<Req*, int>> lasts; // (request, index inside this chunk) of final prompt tokens
+        const size_t left = total - done;
+        float* stage = (float*)stage_alloc(std::min<size_t>(left, (size_t)chunk) * Q3_EMBD * 4);
         while (n < chunk && bi < batch.size()) {
             Req* r = batch[bi];
-            std::copy(r->r.prompt + (size_t)t * Q3_EMBD, r->r.prompt + (size_t)(t + 1) * Q3_EMBD, stage.begin() + (size_t)n * Q3_EMBD);
+            std::copy(r->r.prompt + (size_t)t * Q3_EMBD, r->r.prompt + (size_t)(t + 1) * Q3_EMBD, stage + (size_t)n * Q3_EMBD);
             seq[n] = r->slot; slot[n] = t; pos[4 * n] = pos[4 * n + 1] = pos[4 * n + 2] = t; pos[4 * n + 3] = 0; // :306-314
             if (t == r->r.n_prompt - 1) { lasts.emplace_back(r, n); bi++; t = 0; } else t++;
             n++;
         }
-        Q3_HIP(hipMemcpyAsync(d_prompt_.p, stage.data(), (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
-        Q3_HIP(hipMemcpyAsync(d_pf_seq_.p, seq.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
-        Q3_HIP(hipMemcpyAsync(d_pf_slot_.p, slot.data(), (size_t)n * 4, hipMemcpyHostToDevice, st_));
-        Q3_HIP(hipMemcpyAsync(d_pf_pos_.p, pos.data(), (size_t)n * 16, hipMemcpyHostToDevice, st_));
-        Q3_HIP(hipStreamSynchronize(st_)); // staging vectors are reused by the next chunk
+        Q3_HIP(hipMemcpyAsync(d_prompt_.p, stage, (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_));
+        h2d(d_pf_seq_.p, seq.data(), (size_t)n * 4); h2d(d_pf_slot_.p, slot.data(), (size_t)n * 4); h2d(d_pf_pos_.p, pos.data(), (size_t)n * 16);
         TokMeta tm{d_pf_seq_.p, d_pf_slot_.p, d_pf_pos_.p};
         Transformer::Input in; in.x = d_prompt_.p; in.x_stride = Q3_EMBD;
         talker_->forward(st_, in, n, tm, kv_t_->view(), nullptr);
@@ -304,13 +327,13 @@ void Engine::decoder_main() {
                 if (dq_.empty()) return;
                 grp.push_back(std::move(dq_.front()));
                 dq_.pop_front();
-                if (!grp[0].fence && gmax > 1) {
+                if (!grp[0].fence && !grp[0].reset && gmax > 1) {
                     const size_t nc = grp[0].codes.size();
                     std::vector<Req*> seen{grp[0].r};
                     for (auto it = dq_.begin(); it != dq_.end() && (int)grp.size() < gmax;) {
                         const bool dup = std::find(seen.begin(), seen.end(), it->r) != seen.end();
                         if (!dup) seen.push_back(it->r);
-                        if (!dup && !it->fence && it->codes.size() == nc) { grp.push_back(std::move(*it)); it = dq_.erase(it); }
+                        if (!dup && !it->fence && !it->reset && it->codes.size() == nc) { grp.push_back(std::move(*it)); it = dq_.erase(it); }
                         else ++it;
                     }
                 }
@@ -322,7 +345,8 @@ void Engine::decoder_main() {
                 auto it = last.find(t.r);
                 if (it != last.end() && it->second.first != lane) Q3_HIP(hipStreamWaitEvent(st2_[lane], it->second.second, 0));
             }
-            if (!grp[0].fence) {
+            if (grp[0].reset) codec_->reset_async(st2_[lane], grp[0].r->cs); // AudioDecoder::create_state for a new request
+            else if (!grp[0].fence) {
                 const int nf = (int)grp[0].codes.size() / 16;
                 std::vector<int> streams(G);
                 std::vector<float*> dst(G);
@@ -338,9 +362,11 @@ void Engine::decoder_main() {
                 for (int g = 0; g < G; g++) grp[g].r->pcm_enq += (size_t)std::max(got, 0);
             }
             for (auto& t : grp) {
-                hipEvent_t ev;
-                Q3_HIP(hipEventCreate(&ev));
-                Q3_HIP(hipEventRecord(ev, st2_[lane])); // first one = the reference's first stream_tx.send (:522-523)
+                hipEvent_t ev = nullptr;
+                if (!t.reset) {
+                    Q3_HIP(hipEventCreate(&ev));
+                    Q3_HIP(hipEventRecord(ev, st2_[lane])); // first one = the reference's first stream_tx.send (:522-523)
+                }
                 if (t.fence) { auto it = last.find(t.r); if (it != last.end()) { (void)hipEventDestroy(it->second.second); last.erase(it); } }
                 else {
                     hipEvent_t ord;
@@ -349,6 +375,7 @@ void Engine::decoder_main() {
                     else { ord = it->second.second; it->second.first = lane; }
                     Q3_HIP(hipEventRecord(ord, st2_[lane]));
                 }
+                if (t.reset) continue;
                 std::lock_guard<std::mutex> lk(dmu_);
                 comp_.push_back(Completion{t.r, ev, t.r->pcm_enq, t.fence});
                 if (!t.fence) stats.codec_calls++;
@@ -425,6 +452,10 @@ void Engine::admit() {
     std::vector<Req*> batch;
     {
         std::lock_guard<std::mutex> lk(mu_);
+        // a prefill stalls every running sequence for its duration, so under load admissions are grouped: wait until an eighth of
+        // the slots is free -- unless the engine is idle or the free slots already cover the whole queue
+        const int free_slots = B_ - n_active_, quantum = std::max(1, B_ / 8);
+        if (free_slots < quantum && n_active_ > 0 && free_slots < (int)pending_.size()) return;
         while (!pending_.empty() && n_active_ < B_) {
             Req* r = pending_.front();
             if (r->want_pcm && cs_free_.empty()) break; // every codec stream still drains: admit after the next harvest
@@ -440,6 +471,7 @@ void Engine::admit() {
         }
     }
     if (batch.empty()) return;
+    arena_used_ = 0; // st_ is idle between scheduler operations
     bool sampled = false;
     for (int b = 0; b < B_; b++) if (slot_req_[b] && slot_req_[b]->r.sampler.temperature > 0.0f) sampled = true;
     const q3_u64 armed[17] = {pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
@@ -450,19 +482,22 @@ void Engine::admit() {
     for (Req* r : batch) {
         const int b = r->slot;
         kv_t_->release(b);
-        kv_t_->ensure(b, r->r.n_prompt + r->r.max_steps + 1);
+        kv_t_->ensure(b, r->r.n_prompt + r->r.max_steps + 1, st_);
         h_maxf_[b] = r->r.max_steps; h_fin_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = r->r.n_prompt;
         h_mask_[b] = r->r.mask_eos ? Q3_CODEC_EOS : -1;
         h_temp_[b] = r->r.sampler.temperature; h_topk_[b] = r->r.sampler.top_k; h_topp_[b] = r->r.sampler.top_p;
         StdRng rng(r->seed); // llama/mod.rs:648: the device regenerates this ChaCha12 stream from the key and a draw counter
-        Q3_HIP(hipMemcpy(d_rngkey_.p + (size_t)b * 8, rng.key(), 32, hipMemcpyHostToDevice));
-        Q3_HIP(hipMemcpy(d_draws_.p + b, &zero, 4, hipMemcpyHostToDevice));
-        Q3_HIP(hipMemcpy(d_keys_.p + (size_t)b * 16, armed, 16 * 8, hipMemcpyHostToDevice));
-        Q3_HIP(hipMemcpy(d_next_key0_.p + b, armed, 8, hipMemcpyHostToDevice));
-        if (r->want_pcm) codec_->reset(r->cs);
+        h2d(d_rngkey_.p + (size_t)b * 8, rng.key(), 32);
+        h2d(d_draws_.p + b, &zero, 4);
+        h2d(d_keys_.p + (size_t)b * 16, armed, 16 * 8);
+        h2d(d_next_key0_.p + b, armed, 8);
+        if (r->want_pcm) { // the decoder thread clears the codec stream's state right before the request's first chunk
+            { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, {}, false, false, true}); }
+            dcv_.notify_all();
+        }
         r->chunker.reset(new Chunker([this, r](const int64_t* codes, int n_codes, bool is_final) {
             if (!r->want_pcm) return;
-            { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, std::vector<int64_t>(codes, codes + n_codes), is_final, false}); }
+            { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, std::vector<int64_t>(codes, codes + n_codes), is_final, false, false}); }
             dcv_.notify_all();
         }));
         Q3_HIP(hipEventCreate(&r->ev_admit));
@@ -493,12 +528,12 @@ void Engine::finish_ar(Req* r) { // engine.rs:644-649: final flush of the chunke
         else { r->state = REQ_DONE; r->t_done = now_ms(); cv_.notify_all(); }
     }
     if (r->want_pcm) {
-        { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, {}, false, true}); }
+        { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, {}, false, true, false}); }
         dcv_.notify_all();
     }
     h_fin_[b] = 1; h_maxf_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = 0; h_temp_[b] = 0.0f; h_mask_[b] = -1;
     kv_t_->release(b);
-    kv_t_->ensure(b, 1); // idle slots keep stepping inside the graph; they write to their one reserved page
+    kv_t_->ensure(b, 1, st_); // idle slots keep stepping inside the graph; they write to their one reserved page
     slot_dirty_ = true;
 }
 
@@ -518,6 +553,7 @@ void Engine::run_group() {
             remaining = std::max(remaining, r->r.max_steps - h_nfr_[b]);
             if (r->r.sampler.temperature > 0.0f) sampled = true;
         }
+    arena_used_ = 0; // st_ is idle between scheduler operations: everything staged earlier has been consumed
     if (slot_dirty_) upload_slot_state();
     const int width = pick_width(hi, B_);
     const int group = std::max(1, std::min(4, remaining));
@@ -532,25 +568,32 @@ void Engine::run_group() {
         else Q3_HIP(hipGraphLaunch(fg.exec, st_));
     }
     Q3_HIP(hipEventRecord(e1, st_));
+    // results of the group: frame counters, finished flags and the (at most `group`) new code rows of every active slot
+    const int32_t* p_nfr = (const int32_t*)d2h_begin(d_nframes_.p, (size_t)width * 4);
+    const int32_t* p_fin = (const int32_t*)d2h_begin(d_finished_.p, (size_t)width * 4);
+    std::vector<const int32_t*> p_hist(width, nullptr);
+    for (int b = 0; b < width; b++)
+        if (Req* r = slot_req_[b]) {
+            const int rows = std::min(group, r->r.max_steps - r->fed);
+            if (rows > 0) p_hist[b] = (const int32_t*)d2h_begin(d_hist_.p + (size_t)b * hist_stride_ + (size_t)r->fed * 16, (size_t)rows * 64);
+        }
     Q3_HIP(hipStreamSynchronize(st_));
     { float ms = 0; Q3_HIP(hipEventElapsedTime(&ms, e0, e1)); stats.frame_loop_ms += ms; }
     (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    stats.steps++; stats.slot_frames += (double)width * group;
+    stats.steps++; stats.slot_frames += (double)width * group; stats.graph_frames += group;
     talker_->timer = nullptr; predictor_->timer = nullptr; talker_->timer_gu = nullptr;
     if (instrument_) {
         stats.gemv_ms += timer_.collect_ms(); stats.gemv_bytes += timer_.bytes; stats.gemv_launches += timer_.launches; timer_.bytes = 0; timer_.launches = 0;
         stats.gu_ms += timer_gu_.collect_ms(); stats.gu_bytes += timer_gu_.bytes; stats.gu_launches += timer_gu_.launches; timer_gu_.bytes = 0; timer_gu_.launches = 0;
     }
-    d_nframes_.download(h_nfr_.data(), width); d_finished_.download(h_fin_.data(), width);
-    std::vector<int32_t> hbuf;
+    std::memcpy(h_nfr_.data(), p_nfr, (size_t)width * 4); std::memcpy(h_fin_.data(), p_fin, (size_t)width * 4);
     for (int b = 0; b < width; b++) {
         Req* r = slot_req_[b];
         if (!r) continue;
         if (h_nfr_[b] > r->fed) { // hand new frames to the chunker (engine.rs:613-620)
             const int nnew = h_nfr_[b] - r->fed;
-            hbuf.resize((size_t)nnew * 16);
-            Q3_HIP(hipMemcpy(hbuf.data(), d_hist_.p + (size_t)b * hist_stride_ + (size_t)r->fed * 16, (size_t)nnew * 64, hipMemcpyDeviceToHost));
-            { std::lock_guard<std::mutex> lk(mu_); r->codes.insert(r->codes.end(), hbuf.begin(), hbuf.end()); r->fed = h_nfr_[b]; }
+            const int32_t* hbuf = p_hist[b];
+            { std::lock_guard<std::mutex> lk(mu_); r->codes.insert(r->codes.end(), hbuf, hbuf + (size_t)nnew * 16); r->fed = h_nfr_[b]; }
             for (int f = 0; f < nnew; f++) {
                 int64_t fc[16];
                 for (int q = 0; q < 16; q++) fc[q] = hbuf[(size_t)f * 16 + q];
@@ -562,12 +605,23 @@ void Engine::run_group() {
     }
 }
 
+static double g_t_harvest = 0, g_t_admit = 0, g_t_group = 0, g_t_idle = 0;
+static const bool g_trace = std::getenv("Q3_SCHED_TRACE") != nullptr;
 bool Engine::step() {
     if (codec_ && !dec_started_) { dec_started_ = true; dec_thread_ = std::thread([this] { decoder_main(); }); }
+    const double t0 = now_ms();
     harvest(false);
+    const double t1 = now_ms();
     admit();
+    const double t2 = now_ms();
     if (n_active_ > 0) run_group();
     else if (n_draining_ > 0) harvest(true);
+    const double t3 = now_ms();
+    if (g_trace) {
+        g_t_harvest += t1 - t0; g_t_admit += t2 - t1; (n_active_ > 0 ? g_t_group : g_t_idle) += t3 - t2;
+        fprintf(stderr, "[sched] harvest %.1f admit %.1f group %.1f drain-wait %.1f ms (frame_loop %.1f prefill %.1f)\n", g_t_harvest, g_t_admit, g_t_group, g_t_idle,
+                stats.frame_loop_ms, stats.prefill_ms);
+    }
     std::lock_guard<std::mutex> lk(mu_);
     return n_active_ > 0 || n_draining_ > 0 || !pending_.empty();
 }

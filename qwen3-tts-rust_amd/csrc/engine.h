@@ -53,6 +53,7 @@ struct EngineStats { // accumulated since reset
     double codec_ms = 0; long codec_calls = 0;
     double prefill_ms = 0;
     long steps = 0; double slot_frames = 0;      // scheduler: frame-group launches, sum of graph widths x frames (occupancy)
+    long graph_frames = 0;                       // frame-graph replays
 };
 
 enum ReqState { REQ_QUEUED = 0, REQ_RUNNING = 1, REQ_DRAINING = 2, REQ_DONE = 3, REQ_FAILED = -1 };
@@ -111,6 +112,12 @@ private:
     void finish_ar(Req* r);
     void decoder_main();
     void upload_slot_state();
+    // All scheduler transfers go through a pinned arena on the AR stream: the engine's streams are non-blocking, so nothing the
+    // scheduler does waits for the codec lanes (a synchronous hipMemcpy on the null stream would).
+    void* stage_alloc(size_t bytes);
+    void h2d(void* dst, const void* src, size_t bytes);            // async on st_, source copied into the arena first
+    void* d2h_begin(const void* src, size_t bytes);                // async on st_ into the arena; valid after the next sync of st_
+    unsigned char* arena_ = nullptr; size_t arena_cap_ = 0, arena_used_ = 0;
 
     EngineParams p_;
     hipStream_t st_ = nullptr; int dev_ = 0;
@@ -151,7 +158,7 @@ private:
     std::vector<Voice> voices_;
     std::thread driver_; bool driver_on_ = false, driver_stop_ = false;
     // decoder thread
-    struct DecTask { Req* r; std::vector<int64_t> codes; bool is_final; bool fence; };
+    struct DecTask { Req* r; std::vector<int64_t> codes; bool is_final; bool fence; bool reset; };
     struct Completion { Req* r; hipEvent_t ev; size_t pcm_after; bool fence; };
     std::thread dec_thread_; bool dec_started_ = false, dec_stop_ = false;
     std::mutex dmu_; std::condition_variable dcv_;

@@ -435,9 +435,11 @@ KvPool::KvPool(int n_layer, int n_kv, int n_pages, int n_seq, int max_pages_per_
     const size_t per_page = (size_t)n_layer * n_kv * 8192;
     k_.alloc(per_page * n_pages); v_.alloc(per_page * n_pages);
     k_.zero(); v_.zero();
-    table_.assign((size_t)n_seq * max_pages_per_seq, 0);
-    d_table_.alloc(table_.size());
-    d_table_.upload(table_.data(), table_.size());
+    const size_t nt = (size_t)n_seq * max_pages_per_seq;
+    Q3_HIP(hipHostMalloc((void**)&table_, nt * sizeof(int32_t)));
+    std::fill(table_, table_ + nt, 0);
+    d_table_.alloc(nt);
+    d_table_.upload(table_, nt);
     for (int p = n_pages - 1; p >= 0; p--) free_.push_back(p);
     used_pages_.assign(n_seq, 0);
 }
@@ -457,6 +459,16 @@ void KvPool::ensure(int seq, int n_positions) {
     Q3_CHECK(need <= max_pages_, "sequence exceeds max pages");
     while (used_pages_[seq] < need) { assign(seq, used_pages_[seq], alloc_page()); used_pages_[seq]++; }
 }
+void KvPool::ensure(int seq, int n_positions, hipStream_t st) {
+    const int need = (n_positions + 63) / 64;
+    Q3_CHECK(need <= max_pages_, "sequence exceeds max pages");
+    const int first = used_pages_[seq];
+    while (used_pages_[seq] < need) { table_[(size_t)seq * max_pages_ + used_pages_[seq]] = alloc_page(); used_pages_[seq]++; }
+    if (need > first) // rows of other sequences are untouched, and this row is not rewritten before `st` is synchronised by the caller
+        Q3_HIP(hipMemcpyAsync(d_table_.p + (size_t)seq * max_pages_ + first, table_ + (size_t)seq * max_pages_ + first, (size_t)(need - first) * 4,
+                              hipMemcpyHostToDevice, st));
+}
+KvPool::~KvPool() { if (table_) (void)hipHostFree(table_); }
 void KvPool::release(int seq) {
     for (int i = 0; i < used_pages_[seq]; i++) free_page(table_[(size_t)seq * max_pages_ + i]);
     used_pages_[seq] = 0;

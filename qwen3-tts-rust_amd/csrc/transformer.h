@@ -87,12 +87,15 @@ Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& stora
 class KvPool {
 public:
     KvPool(int n_layer, int n_kv, int n_pages, int n_seq, int max_pages_per_seq);
+    ~KvPool();
+    KvPool(const KvPool&) = delete; KvPool& operator=(const KvPool&) = delete;
     KvCache view() const;
     // host-side page accounting
     int alloc_page();
     void free_page(int p);
     void assign(int seq, int logical_page, int physical_page); // updates host + device table
     void ensure(int seq, int n_positions);                      // make sure pages for [0,n_positions) exist
+    void ensure(int seq, int n_positions, hipStream_t st);      // same; the table row is uploaded asynchronously on `st`
     void release(int seq);
     int pages_free() const { return (int)free_.size(); }
     size_t bytes() const { return (k_.n + v_.n) * 2; }
@@ -100,7 +103,7 @@ private:
     int n_layer_, n_kv_, n_pages_, n_seq_, max_pages_;
     DevBuf<uint16_t> k_, v_;
     DevBuf<int32_t> d_table_;
-    std::vector<int32_t> table_;
+    int32_t* table_ = nullptr; // pinned host mirror of the page table
     std::vector<int> free_;
     std::vector<int> used_pages_; // per seq count
 };

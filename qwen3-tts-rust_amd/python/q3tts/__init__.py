@@ -39,7 +39,7 @@ class Stats(C.Structure):
                 ("gemv_launches", C.c_int64), ("gemv_bytes", C.c_double), ("codec_ms", C.c_double), ("codec_calls", C.c_int64),
                 ("talker_weight_bytes", C.c_double), ("predictor_weight_bytes", C.c_double), ("kv_bytes_per_token", C.c_double),
                 ("gu_ms", C.c_double), ("gu_launches", C.c_int64), ("gu_bytes", C.c_double),
-                ("sched_steps", C.c_int64), ("slot_frames", C.c_double)]
+                ("sched_steps", C.c_int64), ("slot_frames", C.c_double), ("graph_frames", C.c_int64)]
 
 
 class ReqStatus(C.Structure):

@@ -335,6 +335,34 @@ def test_bf16_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     ge.close(); oe.close()
 
 
+def test_bf16_mixed_voice_clone_batch_c5(gpu, oracle, tiny_model, vivian):
+    """BASELINE.json configs[4] mechanics at test size: bf16 weights, 10 concurrent sequences over 3 registered voices (two clone
+    voices with reference codes + reference text, one preset), prompts built engine-side, sampled and greedy mixed."""
+    qdir = os.path.join(tiny_model, "gguf_bf16")
+    ge = gpu.Engine(tiny_model, "bf16", max_batch=10, max_steps=16, load_codec=True)
+    oe = oracle.Engine(qdir, os.path.join(tiny_model, "onnx", "q3tts_codec.gguf"), 4)
+    rng = np.random.default_rng(55)
+    spk2 = (vivian * 0.5 + rng.standard_normal(2048).astype(np.float32) * 0.01).astype(np.float32)
+    voices = [dict(spk=vivian, codes=None, text=None),
+              dict(spk=spk2, codes=rng.integers(0, 2048, 6 * 16).astype(np.int32), text=rng.integers(0, 4000, 4).astype(np.int32)),
+              dict(spk=vivian, codes=rng.integers(0, 2048, 3 * 16).astype(np.int32), text=rng.integers(0, 4000, 2).astype(np.int32))]
+    vids = [ge.register_voice(v["spk"], v["codes"], v["text"]) for v in voices]
+    texts = [rng.integers(0, 4000, 4 + i).astype(np.int32) for i in range(10)]
+    ids = [ge.submit_text(vids[i % 3], t, lang_id=2055, max_steps=5 + i % 3, temperature=(0.8 if i % 4 == 0 else 0.0), top_k=10, top_p=0.9,
+                          seed=90 + i, want_pcm=True) for i, t in enumerate(texts)]
+    while ge.sched_step():
+        pass
+    for i, (t, rid) in enumerate(zip(texts, ids)):
+        v = voices[i % 3]
+        prompt = (ge.assets.build_clone(t, v["codes"], v["text"], v["spk"]) if v["codes"] is not None
+                  else ge.assets.build_core(t, lang_id=2055, spk_emb=v["spk"]))
+        r = ge.result(rid, want_pcm=True)
+        oc, opcm = oe.generate(prompt, max_steps=5 + i % 3, temperature=(0.8 if i % 4 == 0 else 0.0), top_k=10, top_p=0.9, seed=90 + i, want_pcm=True)
+        assert np.array_equal(oc, r["codes"]), i
+        assert np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL, i
+    ge.close(); oe.close()
+
+
 def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
     path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
     rng = np.random.default_rng(8)
