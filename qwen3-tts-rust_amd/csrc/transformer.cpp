@@ -1,5 +1,6 @@
 // transformer.cpp -- see transformer.h.  (compiled by hipcc as HIP: contains the load-time repack kernel)
 #include "transformer.h"
+#include <cstdlib>
 #include <cmath>
 
 namespace q3 {
@@ -167,6 +168,7 @@ float* Transformer::load_f32(const Gguf& g, const std::string& name, int64_t n_e
 }
 
 Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ctx_(n_ctx), max_tok_(max_tok) {
+
     if (const char* e = std::getenv("Q3_UNFUSED")) fused = !(e[0] == '1'); // A/B switch for the parity tests (9 launches/layer)
     Gguf g(path);
     hp_.arch = g.kv_str("general.architecture", "qwen3");
