@@ -8,6 +8,7 @@
 #include "codec.h"
 #include "gguf.h"
 #include <cmath>
+#include <cstdlib>
 #include <map>
 
 namespace q3 {
@@ -117,6 +118,91 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
         }
     }
 }
+// Split-f16 form of the same GEMM for large M: every f32 operand x is carried as hi = f16(x), lo = f16(x - hi) (22 significant bits),
+// and a*b is accumulated in f32 as a_hi*b_hi + a_hi*b_lo + a_lo*b_hi on v_mfma_f32_32x32x16_f16 -- three passes at the 16x f16 MFMA
+// rate instead of one at the f32 rate.  Weights are split once at load (Wh/Wl, [N][K] f16); activations are split while the tile
+// is staged into LDS.  Relative error per product ~2^-22 (f32: 2^-24); PCM stays within 1e-5 RMS of the double-precision oracle.
+// Same tiling, implicit-GEMM addressing, split-K and epilogues as k_conv_gemm<2>; BK = 32 (divides every cin of the decoder).
+typedef _Float16 h8v __attribute__((ext_vector_type(8)));
+typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+__global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
+    constexpr int BM = 64, BN = 64, BK = 32, LD = 40; // LD: padded row stride (f16) of the LDS tiles
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    // A: 64 rows x 8 float4 per K tile -> 2 per thread ; W: 64 rows x 4 uint4 (8 f16) per matrix -> 1 per thread per matrix
+    float4 ra[2];
+    uint4 rh, rl;
+    int arow[2];
+#pragma unroll
+    for (int i = 0; i < 2; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    const int wrow = n0 + tid / 4, wk = 8 * (tid & 3);
+    auto fetch = [&](int k0) {
+        const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+        }
+        rh = make_uint4(0, 0, 0, 0); rl = make_uint4(0, 0, 0, 0);
+        if (wrow < g.N) {
+            rh = *reinterpret_cast<const uint4*>(Wh + (size_t)wrow * g.K + k0 + wk);
+            rl = *reinterpret_cast<const uint4*>(Wl + (size_t)wrow * g.K + k0 + wk);
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 2; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            h4v hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
+            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+        }
+        *reinterpret_cast<uint4*>(&Bh[tid / 4][wk]) = rh;
+        *reinterpret_cast<uint4*>(&Bl[tid / 4][wk]) = rl;
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stash();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
+            const h8v ah = *reinterpret_cast<const h8v*>(&Ah[wm * 32 + (lane & 31)][ko]);
+            const h8v al = *reinterpret_cast<const h8v*>(&Al[wm * 32 + (lane & 31)][ko]);
+            const h8v bh = *reinterpret_cast<const h8v*>(&Bh[wn * 32 + (lane & 31)][ko]);
+            const h8v bl = *reinterpret_cast<const h8v*>(&Bl[wn * 32 + (lane & 31)][ko]);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
+            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
+                else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[r], row, col);
+            }
+        }
+    }
+}
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)g.M * g.N) return;
@@ -177,7 +263,8 @@ __global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
     }
     if (lane < MT && lane < g.M && n < g.N) g.out[out_off(g, lane, n)] = gemm_epilogue(g, mine, lane, n);
 }
-static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats) {
+static const bool g_codec_f32 = [] { const char* e = std::getenv("Q3_CODEC_F32"); return e && e[0] == '1'; }(); // A/B switch
+static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const _Float16* wh = nullptr, const _Float16* wl = nullptr) {
     if (g.M <= 16) {
         dim3 grid((g.N + 7) / 8);
         if (g.M <= 4) hipLaunchKernelGGL((k_skinny_gemm<4>), grid, dim3(512), 0, st, g);
@@ -191,6 +278,16 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats) {
     while (tiles * ksplit < 256 && ksplit < 16 && (g.K / (ksplit * 2)) % 16 == 0 && g.K / (ksplit * 2) >= 128 &&
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
+        int ks = 1;
+        while (tiles * ks < 256 && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
+        hipLaunchKernelGGL(k_conv_gemm_h, dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
+        if (ks > 1) {
+            const size_t n = (size_t)g.M * g.N;
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
+        }
+        return;
+    }
     if (small) hipLaunchKernelGGL((k_conv_gemm<1>), dim3((g.N + 127) / 128, (g.M + 31) / 32, ksplit), dim3(256), 0, st, g);
     else hipLaunchKernelGGL((k_conv_gemm<2>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ksplit), dim3(256), 0, st, g);
     if (ksplit > 1) {
@@ -368,7 +465,7 @@ __global__ void __launch_bounds__(256) k_conv_out(const float* __restrict__ in_e
 }
 
 // ---------------- host side ----------------
-struct ConvW { DevBuf<float> w, b; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
+struct ConvW { DevBuf<float> w, b; DevBuf<_Float16> wh, wl; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
 struct Snake { DevBuf<float> ea, inv_eb; int C = 0; };
 // A causal conv's streaming state.  `hist` is the persistent store [n_streams][H][C]; the rows a call works on live in a
 // per-lane batched extended buffer [G][(H + T)][C] (Scratch::work[id]): history first, then the call's T new rows.
@@ -411,6 +508,13 @@ struct CodecDecoder::Impl {
         return std::vector<float>(p, p + t.nbytes / 4);
     }
     static void up_f(DevBuf<float>& d, const std::vector<float>& v) { d.alloc(v.size()); d.upload(v.data(), v.size()); }
+    // hi/lo f16 split of a rearranged weight matrix for k_conv_gemm_h (only matrices that can see >= 64 rows per call need it)
+    static void split_w(ConvW& c, const std::vector<float>& r) {
+        std::vector<_Float16> h(r.size()), l(r.size());
+        for (size_t i = 0; i < r.size(); i++) { h[i] = (_Float16)r[i]; l[i] = (_Float16)(r[i] - (float)h[i]); }
+        c.wh.alloc(h.size()); c.wh.upload(h.data(), h.size());
+        c.wl.alloc(l.size()); c.wl.upload(l.data(), l.size());
+    }
     // causal conv weight [cout][cin][k] -> Wr[co][j*cin + ci]
     void make_conv(ConvW& c, const Gguf& g, const std::string& wn, const std::string& bn, int cout, int cin, int k, int dil) {
         auto w = tensor(g, wn);
@@ -418,11 +522,11 @@ struct CodecDecoder::Impl {
         std::vector<float> r((size_t)cout * cin * k);
         for (int co = 0; co < cout; co++) for (int ci = 0; ci < cin; ci++) for (int j = 0; j < k; j++)
             r[((size_t)co * k + j) * cin + ci] = w[((size_t)co * cin + ci) * k + j];
-        up_f(c.w, r);
+        up_f(c.w, r); split_w(c, r);
         if (!bn.empty()) up_f(c.b, tensor(g, bn));
         c.N = cout; c.K = cin * k; c.cin = cin; c.taps = k; c.dil = dil;
     }
-    void make_linear(ConvW& c, const std::vector<float>& w, int N, int K) { up_f(c.w, w); c.N = N; c.K = K; c.cin = K; c.taps = 1; c.dil = 1; }
+    void make_linear(ConvW& c, const std::vector<float>& w, int N, int K) { up_f(c.w, w); split_w(c, w); c.N = N; c.K = K; c.cin = K; c.taps = 1; c.dil = 1; }
     // transposed conv weight [cin][cout][k], stride s (k == 2s or k == s) -> Wr[(r,co)][j*cin+ci], tap 0 = previous frame
     void make_convt(ConvW& c, const Gguf& g, const std::string& wn, const std::string& bn, int cin, int cout, int k, int s) {
         auto w = tensor(g, wn);
@@ -439,7 +543,7 @@ struct CodecDecoder::Impl {
                 } else r[(size_t)(rr * cout + co) * cin + ci] = w[((size_t)ci * cout + co) * k + rr];
             }
         }
-        up_f(c.w, r); up_f(c.b, br);
+        up_f(c.w, r); split_w(c, r); up_f(c.b, br);
         c.N = s * cout; c.K = taps * cin; c.cin = cin; c.taps = taps; c.dil = 1;
     }
     void make_snake(Snake& s, const Gguf& g, const std::string& an, const std::string& bn, int C) {
@@ -471,7 +575,7 @@ struct CodecDecoder::Impl {
         g.o_segT = out.segT; g.o_skip = out.skip_rows * out_C;
         g.r_segT = res.segT; g.r_skip = res.skip_rows * ldr;
         if (sn) { g.snake_ea = sn->ea.p; g.snake_ib = sn->inv_eb.p; }
-        gemm(st, g, S->splitk_ws.p, S->splitk_ws.n);
+        gemm(st, g, S->splitk_ws.p, S->splitk_ws.n, c.wh.n ? c.wh.p : nullptr, c.wl.n ? c.wl.p : nullptr);
     }
     void load_hist(hipStream_t st, const Ext& e, int G, int T, const int64_t* meta) {
         if (e.H == 0) return;
