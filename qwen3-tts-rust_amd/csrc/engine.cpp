@@ -733,6 +733,10 @@ void Engine::generate_batch(const std::vector<GenRequest>& reqs, std::vector<Gen
     Q3_CHECK(n >= 1, "no requests");
     Q3_CHECK(!driver_on_, "generate_batch cannot be mixed with a running scheduler thread");
     out.assign(n, GenResult());
+    for (const GenRequest& g : reqs) { // validate everything before anything is queued
+        Q3_CHECK(g.prompt && g.n_prompt >= 1 && g.n_prompt <= p_.max_prompt, "prompt length out of range");
+        Q3_CHECK(g.max_steps >= 0 && g.max_steps <= p_.max_steps, "max_steps out of range");
+    }
     std::vector<int64_t> ids(n);
     for (int i = 0; i < n; i++) ids[i] = submit(reqs[i], want_pcm, false);
     double t_ar_end = 0;

@@ -284,6 +284,30 @@ def test_scheduler_driver_thread_and_voices(tiny_engines, vivian):
         assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
 
 
+def test_engine_limits_and_errors(gpu, oracle, tiny_model, vivian):
+    """maximum prompt length (1024 rows = the reference's effective cap, llama/mod.rs:567-581), over-long prompts and out-of-range
+    max_steps are rejected with an error (nothing aborts across the C ABI), unknown request ids fail cleanly"""
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=2, max_prompt=1024, max_steps=8, load_codec=False)
+    oe = oracle.Engine(os.path.join(tiny_model, "gguf_q8_0"), None, 4)
+    rng = np.random.default_rng(77)
+    long_prompt = ge.assets.build_core(rng.integers(0, 4000, 1024 - 11).astype(np.int32), lang_id=2055, spk_emb=vivian)
+    assert long_prompt.shape[0] == 1024
+    short = ge.assets.build_core(np.array([1, 2, 3], np.int32), lang_id=2055, spk_emb=vivian)
+    res = ge.generate_batch([long_prompt, short], max_steps=3, mask_eos=True)      # 1024-row prefill (4 chunks of 256) next to a 14-row one
+    for p, r in zip((long_prompt, short), res):
+        oc, _ = oe.generate(p, max_steps=3, mask_eos=True)
+        assert np.array_equal(oc, r["codes"])
+    too_long = np.concatenate([long_prompt, long_prompt[:1]])
+    with pytest.raises(gpu_mod().Q3Error):
+        ge.generate_batch([too_long], max_steps=2)
+    with pytest.raises(gpu_mod().Q3Error):
+        ge.generate_batch([short], max_steps=9)                                   # engine was built for max_steps=8
+    with pytest.raises(gpu_mod().Q3Error):
+        ge.poll(123456)
+    assert np.array_equal(ge.generate_batch([short], max_steps=3)[0]["codes"], res[1]["codes"])   # still usable after the errors
+    ge.close(); oe.close()
+
+
 def test_engine_wide_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
     """18 concurrent sequences: the batched-step kernels (int8-MFMA GEMM with token-tile loop, gate/up GEMM with the SwiGLU+quant
     epilogue, fused attention for many sequences, multi-token projection) and 16-stream codec groups, against oracle singles."""
