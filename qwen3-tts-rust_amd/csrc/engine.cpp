@@ -610,6 +610,7 @@ void Engine::run_group() {
 static double g_t_harvest = 0, g_t_admit = 0, g_t_group = 0, g_t_idle = 0;
 static const bool g_trace = std::getenv("Q3_SCHED_TRACE") != nullptr;
 bool Engine::step() {
+    std::lock_guard<std::mutex> step_lock(step_mu_);
     if (codec_ && !dec_started_) { dec_started_ = true; dec_thread_ = std::thread([this] { decoder_main(); }); }
     const double t0 = now_ms();
     harvest(false);

@@ -149,6 +149,7 @@ private:
     bool slot_dirty_ = false;
     // scheduler state
     std::mutex mu_; std::condition_variable cv_;
+    std::mutex step_mu_;               // step() is driven by one thread at a time (driver thread, wait() callers, generate_batch)
     std::map<int64_t, std::unique_ptr<Req>> reqs_;
     std::deque<Req*> pending_;
     std::vector<Req*> slot_req_;
