@@ -132,6 +132,26 @@ def numpy_mel(audio):
     return np.array(out, np.float32)
 
 
+def test_mel_matches_transformers_audio_utils(oracle):
+    """Independent pin of row a16: the installed `transformers.audio_utils` builds the same Slaney-scale, Slaney-normalised 128-filter
+    bank (0-12 kHz, 513 bins) and a Hann/1024/256 power-1 spectrogram; the oracle's mel of a chirp must agree with it.  Framing differs
+    only in the padding rule (reference: reflect pad 384 by hand, onnx.rs:255-271), so the clip is pre-padded the reference's way."""
+    from transformers.audio_utils import mel_filter_bank, spectrogram, window_function
+    rng = np.random.default_rng(5)
+    t = np.arange(24000) / 24000.0
+    audio = (0.4 * np.sin(2 * np.pi * (300 + 2500 * t) * t) + 0.02 * rng.standard_normal(t.size)).astype(np.float32)
+    pad = 384
+    padded = np.concatenate([audio[pad:0:-1], audio, audio[-2:-pad - 2:-1]]).astype(np.float64)
+    fb = mel_filter_bank(num_frequency_bins=513, num_mel_filters=128, min_frequency=0.0, max_frequency=12000.0, sampling_rate=24000,
+                         norm="slaney", mel_scale="slaney")
+    spec = spectrogram(padded, window_function(1024, "hann", periodic=True), frame_length=1024, hop_length=256, fft_length=1024, power=1.0,
+                       center=False, mel_filters=fb, mel_floor=1e-5, log_mel="log")
+    ref = spec.T.astype(np.float32)                       # [frames][128]
+    got = oracle.mel(audio)
+    assert got.shape == ref.shape
+    assert np.abs(got - ref).max() < 5e-3                 # |FFT| gets +1e-9 under the root in the reference; f32 vs f64 pipelines
+
+
 def test_mel_matches_numpy_restatement(oracle):
     rng = np.random.default_rng(11)
     t = np.arange(24000 * 2) / 24000.0
