@@ -125,8 +125,10 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
 // Same tiling, implicit-GEMM addressing, split-K and epilogues as k_conv_gemm<2>; BK = 32 (divides every cin of the decoder).
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
+template <int MR> // MR = 32-row tiles per wave along M: workgroup tile (64*MR) x 64; MR = 2 halves the weight re-reads and the LDS traffic per MFMA
 __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
-    constexpr int BM = 64, BN = 64, BK = 32, LD = 40; // LD: padded row stride (f16) of the LDS tiles
+    constexpr int BM = 64 * MR, BN = 64, BK = 32, LD = 40; // LD: padded row stride (f16) of the LDS tiles
+    constexpr int NA = BM * 8 / 256;                        // float4 fetches of A per thread per K tile
     __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
     __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
     __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
@@ -135,20 +137,21 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
     const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
-    f32x16 acc;
+    f32x16 acc[MR];
 #pragma unroll
-    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
-    // A: 64 rows x 8 float4 per K tile -> 2 per thread ; W: 64 rows x 4 uint4 (8 f16) per matrix -> 1 per thread per matrix
-    float4 ra[2];
+    for (int t = 0; t < MR; t++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[t][i] = 0.0f;
+    float4 ra[NA];
     uint4 rh, rl;
-    int arow[2];
+    int arow[NA];
 #pragma unroll
-    for (int i = 0; i < 2; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
     const int wrow = n0 + tid / 4, wk = 8 * (tid & 3);
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
@@ -161,7 +164,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
     };
     auto stash = [&]() {
 #pragma unroll
-        for (int i = 0; i < 2; i++) {
+        for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             h4v hi, lo;
@@ -181,26 +184,32 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
-            const h8v ah = *reinterpret_cast<const h8v*>(&Ah[wm * 32 + (lane & 31)][ko]);
-            const h8v al = *reinterpret_cast<const h8v*>(&Al[wm * 32 + (lane & 31)][ko]);
             const h8v bh = *reinterpret_cast<const h8v*>(&Bh[wn * 32 + (lane & 31)][ko]);
             const h8v bl = *reinterpret_cast<const h8v*>(&Bl[wn * 32 + (lane & 31)][ko]);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc, 0, 0, 0);
-            acc = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc, 0, 0, 0);
+#pragma unroll
+            for (int t = 0; t < MR; t++) {
+                const int ar = (wm * MR + t) * 32 + (lane & 31);
+                const h8v ah = *reinterpret_cast<const h8v*>(&Ah[ar][ko]);
+                const h8v al = *reinterpret_cast<const h8v*>(&Al[ar][ko]);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[t], 0, 0, 0);
+                acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
+            }
         }
         __syncthreads();
     }
     const int col = n0 + wn * 32 + (lane & 31);
     if (col < g.N) {
 #pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) {
-                if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
-                else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[r], row, col);
+        for (int t = 0; t < MR; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wm * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][r];
+                    else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[t][r], row, col);
+                }
             }
-        }
     }
 }
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
@@ -279,9 +288,14 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
+        static const int big_m = [] { const char* e = std::getenv("Q3_CODEC_BM128"); return e ? atoi(e) : 1024; }(); // rows from which the 128-row tile is used
+        // measured inside the 64-stream pipeline: N = 768 (K = 5376) 96 -> 64 us with the tall tile, N <= 384 no gain
+        const bool tall = g.M >= big_m && g.N >= 512 && ((g.N + 63) / 64) * ((g.M + 127) / 128) >= 160;
+        const int t2 = tall ? ((g.N + 63) / 64) * ((g.M + 127) / 128) : tiles;
         int ks = 1;
-        while (tiles * ks < 256 && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
-        hipLaunchKernelGGL(k_conv_gemm_h, dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
+        while (t2 * ks < 256 && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
+        if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
+        else hipLaunchKernelGGL((k_conv_gemm_h<1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
         if (ks > 1) {
             const size_t n = (size_t)g.M * g.N;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
