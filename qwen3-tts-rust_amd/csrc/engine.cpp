@@ -35,6 +35,7 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     // experiment switch: fold the predictor's attention into its o-proj launch (k_oproj_attn).  Measured on MI355X: 3.23 vs
     // 3.07 ms/frame -- the single-wave attention chain costs more than the launch it removes, so it stays off by default.
     if (const char* e = std::getenv("Q3_FOLD_ATTN")) predictor_->set_short_context(e[0] == '1');
+    if (const char* e = std::getenv("Q3_PRED_FUSED_MAX")) predictor_->set_fused_max_tokens(atoi(e)); // experiment knob
     // Tried and rejected for the predictor's <= 17 cached positions: a single-wave attention kernel (no workgroup barriers, two q heads
     // per wave).  Measured on MI355X: 3.24 vs 3.06 ms/frame -- the serial PV of both heads costs more than the barriers it removes.
     Q3_CHECK(talker_->hp().n_embd == Q3_EMBD, "talker n_embd must be 2048 (reference hard-codes 2048-wide rows)");

@@ -266,7 +266,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
     if (float_mode_) { last_fused_ = false; last_ntok_ = ntok; forward_float(st, in, ntok, tm, kv, hidden_out); return; }
-    const bool use_fused = fused && ntok <= 8; // batched steps (ntok > 8) take the weight-stationary token-sweep GEMM path
+    const bool use_fused = fused && ntok <= fused_max_tok_; // batched steps (ntok > 8) take the weight-stationary token-sweep GEMM path
     last_fused_ = use_fused; last_ntok_ = ntok;
     if (use_fused) {
         // residual stream ping-pongs h_ <-> h2_: a fused prologue may not overwrite what other workgroups still read

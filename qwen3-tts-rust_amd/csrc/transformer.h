@@ -43,6 +43,9 @@ public:
     void set_same_seq_tokens(bool v) { same_seq_ = v; }
     // every cached context of this model stays <= 64 positions (the code predictor): fold attention into the o-proj launch
     void set_short_context(bool v) { short_ctx_ = v; }
+    // largest token count that still takes the 5-launch fused layer path (its GEMVs re-read the weights once per 4-8 token tile,
+    // which is fine for a model whose weights stay cache-resident, i.e. the code predictor)
+    void set_fused_max_tokens(int n) { fused_max_tok_ = n; }
 
     LaunchTimer* timer = nullptr;    // optional per-GEMV-launch event timing (instrumented bench leg): whole GEMV family
     LaunchTimer* timer_gu = nullptr; // ... and the gate/up kernel alone (the dominant launch by bytes)
@@ -73,7 +76,7 @@ private:
     DevBuf<int32_t> d_mrope_;
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
-    bool same_seq_ = false; bool short_ctx_ = false; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
+    bool same_seq_ = false; bool short_ctx_ = false; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
     std::map<const uint8_t*, uint8_t*> mat_meta_, mat_types_;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
