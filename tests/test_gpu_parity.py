@@ -284,6 +284,41 @@ def test_scheduler_driver_thread_and_voices(tiny_engines, vivian):
         assert np.array_equal(oc, r["codes"]) and np.sqrt(np.mean((opcm - r["pcm"]) ** 2)) < PCM_RMS_TOL
 
 
+def test_scheduler_soak_is_deterministic(gpu, tiny_model, vivian):
+    """120 requests (random lengths 0..12, greedy and sampled, with/without PCM) through 8 slots with the background driver thread
+    while the client streams partial results; every request must equal the same request run alone afterwards (batch invariance +
+    no cross-talk between slots, codec streams or RNG states under continuous admission/retirement)."""
+    import time
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=8, max_steps=16, load_codec=True)
+    rng = np.random.default_rng(2024)
+    specs = []
+    for i in range(120):
+        prompt = ge.assets.build_core(rng.integers(0, 4000, int(rng.integers(1, 40))).astype(np.int32), lang_id=2055, spk_emb=vivian)
+        specs.append(dict(prompt=prompt, max_steps=int(rng.integers(0, 13)), temperature=float(rng.choice([0.0, 0.7, 1.1])), top_k=int(rng.choice([0, 5, 40])),
+                          top_p=float(rng.choice([0.8, 1.0])), seed=int(rng.integers(0, 1 << 30)), mask_eos=bool(rng.integers(0, 2)), want_pcm=bool(i % 3)))
+    ge.sched_start()
+    try:
+        ids = []
+        for i, sp in enumerate(specs):
+            ids.append(ge.submit(**sp))
+            if i % 16 == 15:
+                time.sleep(0.002)                                   # arrivals in bursts
+                st = ge.poll(ids[i - 8])
+                ge.fetch(ids[i - 8], 0, max(st["n_frames"], 1), 0, int(st["n_pcm"]))   # streaming reads race with the driver by design
+        for rid in ids:
+            assert ge.wait(rid, 120000.0)
+    finally:
+        ge.sched_stop()
+    results = [ge.result(rid, want_pcm=sp["want_pcm"]) for rid, sp in zip(ids, specs)]
+    for sp, r in zip(specs[::3] + specs[1::7], results[::3] + results[1::7]):
+        alone = ge.generate_batch([sp["prompt"]], max_steps=sp["max_steps"], temperature=sp["temperature"], top_k=sp["top_k"], top_p=sp["top_p"],
+                                  seed=sp["seed"], mask_eos=sp["mask_eos"], want_pcm=sp["want_pcm"])[0]
+        assert np.array_equal(alone["codes"], r["codes"])
+        if sp["want_pcm"]:
+            assert alone["pcm"].size == r["pcm"].size and (r["pcm"].size == 0 or np.sqrt(np.mean((alone["pcm"] - r["pcm"]) ** 2)) < PCM_RMS_TOL)
+    ge.close()
+
+
 def test_engine_limits_and_errors(gpu, oracle, tiny_model, vivian):
     """maximum prompt length (1024 rows = the reference's effective cap, llama/mod.rs:567-581), over-long prompts and out-of-range
     max_steps are rejected with an error (nothing aborts across the C ABI), unknown request ids fail cleanly"""
