@@ -155,11 +155,11 @@ AudioSample TtsEngine::generate_with_voice(const std::string& text, const VoiceF
     return generate_with_voice_ids(ids, voice, instruct ? &ins : nullptr, voice.audio_codes.empty() ? nullptr : &rt);
 }
 
-AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins,
-                                               const std::vector<int32_t>* ref_text_ids, std::vector<int32_t>* codes_out) {
+int TtsEngine::build_prompt(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins,
+                            const std::vector<int32_t>* ref_text_ids, std::vector<float>& prompt) const {
     const q3tts_assets* a = q3tts_engine_assets(e_);
     const int max_rows = 1024;
-    std::vector<float> prompt((size_t)max_rows * 2048);
+    prompt.assign((size_t)max_rows * 2048, 0.0f);
     int n;
     if (voice.audio_codes.empty()) // engine.rs:398-412: Chinese lang id 2055, speaker injected as marker + spk_emb
         n = q3tts_prompt_build_core(a, text_ids.data(), (int)text_ids.size(), 2055, -1, voice.speaker_embedding.data(), ins ? ins->data() : nullptr,
@@ -171,10 +171,20 @@ AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_
                                      voice.speaker_embedding.data(), 2055, ins ? ins->data() : nullptr, ins ? (int)ins->size() : 0, prompt.data(), max_rows);
     }
     if (n < 0) throw std::runtime_error(q3tts_last_error());
-    q3tts_request r{};
+    return n;
+}
+void TtsEngine::fill_request(q3tts_request& r, const std::vector<float>& prompt, int n) const {
     r.prompt = prompt.data(); r.n_prompt = n; r.max_steps = (int)max_steps_;
     r.sampler.temperature = sampler_.temperature; r.sampler.top_k = sampler_.top_k; r.sampler.top_p = sampler_.top_p;
     r.sampler.has_seed = sampler_.seed ? 1 : 0; r.sampler.seed = sampler_.seed.value_or(0);
+}
+
+AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins,
+                                               const std::vector<int32_t>* ref_text_ids, std::vector<int32_t>* codes_out) {
+    std::vector<float> prompt;
+    const int n = build_prompt(text_ids, voice, ins, ref_text_ids, prompt);
+    q3tts_request r{};
+    fill_request(r, prompt, n);
     std::vector<int32_t> codes(max_steps_ * 16);
     AudioSample out;
     out.samples.resize(max_steps_ * 1920);
@@ -183,6 +193,44 @@ AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_
     out.samples.resize((size_t)r.n_pcm);
     if (codes_out) codes_out->assign(codes.begin(), codes.begin() + (size_t)r.n_frames * 16);
     return out; // AudioSample{samples, 24000, 1}: engine.rs:651-655
+}
+
+AudioSample TtsEngine::generate_with_voice_ids_stream(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const ChunkFn& on_chunk,
+                                                      const std::vector<int32_t>* ins, const std::vector<int32_t>* ref_text_ids,
+                                                      std::vector<int32_t>* codes_out) {
+    std::vector<float> prompt;
+    const int n = build_prompt(text_ids, voice, ins, ref_text_ids, prompt);
+    q3tts_request r{};
+    fill_request(r, prompt, n);
+    int64_t id = 0;
+    if (q3tts_submit(e_, &r, 1, &id) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    AudioSample out;
+    std::vector<float> buf(4 * 1920 * 4);
+    for (;;) {
+        int32_t busy = 0;
+        if (q3tts_sched_step(e_, &busy) != Q3TTS_OK) { q3tts_release(e_, id); throw std::runtime_error(q3tts_last_error()); }
+        q3tts_req_status st{};
+        if (q3tts_poll(e_, id, &st) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+        while ((int64_t)out.samples.size() < st.n_pcm) { // hand over whatever the codec finished since the last look
+            int64_t got = 0;
+            if (q3tts_fetch(e_, id, nullptr, 0, 0, buf.data(), (int64_t)out.samples.size(), (int64_t)buf.size(), nullptr, &got) != Q3TTS_OK)
+                throw std::runtime_error(q3tts_last_error());
+            if (got <= 0) break;
+            if (on_chunk) on_chunk(buf.data(), (size_t)got);
+            out.samples.insert(out.samples.end(), buf.begin(), buf.begin() + got);
+        }
+        if (st.state == Q3TTS_REQ_DONE && (int64_t)out.samples.size() >= st.n_pcm) {
+            if (codes_out) {
+                codes_out->assign((size_t)st.n_frames * 16, 0);
+                int32_t gf = 0;
+                q3tts_fetch(e_, id, codes_out->data(), 0, st.n_frames, nullptr, 0, 0, &gf, nullptr);
+            }
+            break;
+        }
+        if (st.state == Q3TTS_REQ_FAILED) { q3tts_release(e_, id); throw std::runtime_error("generation failed"); }
+    }
+    q3tts_release(e_, id);
+    return out;
 }
 
 VoiceFile TtsEngine::create_voice_file(const std::string&, const std::string&) {

@@ -53,10 +53,19 @@ public:
     AudioSample generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice,
                                         const std::vector<int32_t>* instruct_ids = nullptr, const std::vector<int32_t>* ref_text_ids = nullptr,
                                         std::vector<int32_t>* codes_out = nullptr);
+    // Streaming form (the reference keeps its `stream_tx` private and always None, engine.rs:442; SURVEY row f-4 asks for a public
+    // one): on_chunk receives every decoded chunk (4 frames = 7680 samples, fewer for the tail) as soon as the codec has produced it.
+    using ChunkFn = std::function<void(const float* pcm, size_t n_samples)>;
+    AudioSample generate_with_voice_ids_stream(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const ChunkFn& on_chunk,
+                                               const std::vector<int32_t>* instruct_ids = nullptr, const std::vector<int32_t>* ref_text_ids = nullptr,
+                                               std::vector<int32_t>* codes_out = nullptr);
     // create_voice_file -- :324-387: needs the codec/speaker encoder graphs (not in this build)
     VoiceFile create_voice_file(const std::string& audio_path, const std::string& ref_text);
 private:
     TtsEngine() = default;
+    int build_prompt(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins, const std::vector<int32_t>* ref_text_ids,
+                     std::vector<float>& prompt) const;
+    void fill_request(q3tts_request& r, const std::vector<float>& prompt, int n) const;
     q3tts_engine* e_ = nullptr;
     Tokenizer tok_;
     std::map<std::string, VoiceFile> speakers_;

@@ -1,0 +1,42 @@
+// Exercises the C++ host mirror of the reference API (qwen3-tts-rust_amd/host/tts_engine.hpp) on the tiny model:
+// TtsEngine::new_, load_speakers / get_speaker (vivian fallback), set_sampler_config, set_max_steps, generate_with_voice_ids
+// (preset and clone voices), the streaming form, create_voice_file's error, AudioSample::save_wav.  Prints the codes for the
+// Python test to compare with the ctypes path.
+#include "../../qwen3-tts-rust_amd/host/tts_engine.hpp"
+#include <cstdio>
+#include <stdexcept>
+
+int main(int argc, char** argv) {
+    using namespace q3tts;
+    if (argc < 4) { fprintf(stderr, "usage: host_mirror_main <model_dir> <speakers_dir> <out.wav>\n"); return 2; }
+    try {
+        TtsEngine eng = TtsEngine::new_(argv[1], "q8_0");
+        eng.load_speakers(argv[2]);
+        const VoiceFile& v = eng.get_speaker("no-such-speaker");           // falls back to vivian (engine.rs:211-231)
+        if (v.speaker_embedding.size() != 2048) throw std::runtime_error("speaker embedding size");
+        SamplerConfig sc; sc.temperature = 0.0f; sc.seed = 42;
+        eng.set_sampler_config(sc);
+        eng.set_max_steps(10);
+        std::vector<int32_t> ids;
+        for (int i = 0; i < 8; i++) ids.push_back(100 + i);
+        std::vector<int32_t> codes, codes2, codes3;
+        AudioSample a = eng.generate_with_voice_ids(ids, v, nullptr, nullptr, &codes);
+        size_t n_chunks = 0, streamed = 0;
+        AudioSample b = eng.generate_with_voice_ids_stream(ids, v, [&](const float*, size_t n) { n_chunks++; streamed += n; }, nullptr, nullptr, &codes2);
+        if (codes != codes2 || a.samples != b.samples || streamed != b.samples.size() || n_chunks < 2) throw std::runtime_error("streaming result differs");
+        VoiceFile clone = v;                                                // clone voice: reference codes + reference text ids
+        for (int i = 0; i < 3 * 16; i++) clone.audio_codes.push_back((i * 37) % 2048);
+        std::vector<int32_t> ref_text = {7, 8, 9};
+        sc.temperature = 0.7f; eng.set_sampler_config(sc);                  // sampled, seeded
+        AudioSample c = eng.generate_with_voice_ids(ids, clone, nullptr, &ref_text, &codes3);
+        try { eng.create_voice_file("x.wav", "hello"); throw std::runtime_error("create_voice_file should fail"); }
+        catch (const std::runtime_error& e) { if (std::string(e.what()).find("AudioEncoder not loaded") == std::string::npos) throw; }
+        a.save_wav(argv[3]);
+        printf("PRESET");
+        for (int32_t x : codes) printf(" %d", x);
+        printf("\nCLONE");
+        for (int32_t x : codes3) printf(" %d", x);
+        printf("\nPCM %zu %zu chunks %zu duration %.3f\nOK\n", a.samples.size(), c.samples.size(), n_chunks, a.duration());
+    } catch (const std::exception& e) { fprintf(stderr, "FAILED: %s\n", e.what()); return 1; }
+    return 0;
+}

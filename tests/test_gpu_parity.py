@@ -319,6 +319,35 @@ def test_scheduler_soak_is_deterministic(gpu, tiny_model, vivian):
     ge.close()
 
 
+def test_cpp_host_mirror_matches_ctypes_path(gpu, tiny_model, vivian, tmp_path):
+    """The C++ mirror of TtsEngine / VoiceFile / AudioSample (the drop-in surface of src/tts) drives the same C ABI: its codes must
+    equal the ctypes path's for a preset voice (greedy) and a clone voice (sampled, seeded); streaming must equal blocking."""
+    import struct
+    pkg = os.path.join(ROOT, "qwen3-tts-rust_amd")
+    exe = str(tmp_path / "host_mirror_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host", "host_mirror_main.cpp"),
+                           "-L" + pkg, "-lq3tts_host", "-lq3tts", "-Wl,-rpath," + pkg])
+    wav = str(tmp_path / "out.wav")
+    r = subprocess.run([exe, tiny_model, os.path.join(ROOT, "tests", "golden", "speakers"), wav], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines()}
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=1, max_steps=16, load_codec=True)
+    ids = np.arange(100, 108, dtype=np.int32)
+    ref = ge.generate_batch([ge.assets.build_core(ids, lang_id=2055, spk_emb=vivian)], max_steps=10, temperature=0.0, seed=42, mask_eos=False, want_pcm=True)[0]
+    assert np.array_equal(np.array(lines["PRESET"], np.int32).reshape(-1, 16), ref["codes"])
+    clone_codes = (np.arange(48) * 37) % 2048
+    refc = ge.generate_batch([ge.assets.build_clone(ids, clone_codes, np.array([7, 8, 9], np.int32), vivian)], max_steps=10, temperature=0.7, top_k=40, top_p=0.9,
+                             seed=42, mask_eos=False)[0]
+    assert np.array_equal(np.array(lines["CLONE"], np.int32).reshape(-1, 16), refc["codes"])
+    raw = open(wav, "rb").read()
+    assert raw[:4] == b"RIFF" and raw[8:16] == b"WAVEfmt " and struct.unpack("<I", raw[24:28])[0] == 24000
+    n = (len(raw) - 44) // 2
+    assert n == ref["pcm"].size == int(lines["PCM"][0])
+    pcm16 = np.frombuffer(raw[44:], np.int16)
+    assert np.abs(pcm16.astype(np.float32) - np.clip(ref["pcm"] * 32767.0, -32768, 32767)).max() <= 1.0     # audio.rs:36 scaling, truncation
+    ge.close()
+
+
 def test_engine_limits_and_errors(gpu, oracle, tiny_model, vivian):
     """maximum prompt length (1024 rows = the reference's effective cap, llama/mod.rs:567-581), over-long prompts and out-of-range
     max_steps are rejected with an error (nothing aborts across the C ABI), unknown request ids fail cleanly"""
