@@ -105,6 +105,66 @@ void AudioSample::save_wav(const std::string& path) const { // audio.rs:26-41
     fclose(f);
 }
 
+// ---------------- utils/cache.rs ----------------
+namespace cache {
+void save_cache(const std::string& path, const std::vector<int64_t>& codes, const std::vector<float>& emb) {
+    FILE* f = fopen(path.c_str(), "wb");
+    if (!f) throw std::runtime_error("cannot create " + path);
+    const uint32_t version = 1;
+    const uint64_t nc = codes.size(), ne = emb.size();
+    fwrite("TTSC", 1, 4, f); fwrite(&version, 4, 1, f);
+    fwrite(&nc, 8, 1, f); if (nc) fwrite(codes.data(), 8, nc, f);
+    fwrite(&ne, 8, 1, f); if (ne) fwrite(emb.data(), 4, ne, f);
+    fclose(f);
+}
+void load_cache(const std::string& path, std::vector<int64_t>& codes, std::vector<float>& emb) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    auto fail = [&](const char* m) { fclose(f); throw std::runtime_error(m); };
+    char magic[4]; uint32_t version = 0; uint64_t n = 0;
+    if (fread(magic, 1, 4, f) != 4) fail("failed to fill whole buffer");
+    if (memcmp(magic, "TTSC", 4) != 0) fail("Invalid magic bytes");
+    if (fread(&version, 4, 1, f) != 1) fail("failed to fill whole buffer");
+    if (version != 1) fail("Unsupported version");
+    if (fread(&n, 8, 1, f) != 1 || n > (1ull << 32)) fail("failed to fill whole buffer");
+    codes.resize(n);
+    if (n && fread(codes.data(), 8, n, f) != n) fail("failed to fill whole buffer");
+    if (fread(&n, 8, 1, f) != 1 || n > (1ull << 32)) fail("failed to fill whole buffer");
+    emb.resize(n);
+    if (n && fread(emb.data(), 4, n, f) != n) fail("failed to fill whole buffer");
+    fclose(f);
+}
+} // namespace cache
+
+AudioSample AudioSample::load_wav(const std::string& path) { // audio.rs:11-23 (RIFF/WAVE PCM chunks; samples interpreted as i16)
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("cannot open " + path);
+    std::vector<unsigned char> d;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    if (d.size() < 12 || memcmp(d.data(), "RIFF", 4) != 0 || memcmp(d.data() + 8, "WAVE", 4) != 0) throw std::runtime_error("no RIFF tag found");
+    AudioSample a;
+    bool have_fmt = false;
+    for (size_t p = 12; p + 8 <= d.size();) {
+        uint32_t len; memcpy(&len, d.data() + p + 4, 4);
+        const unsigned char* body = d.data() + p + 8;
+        const size_t avail = std::min<size_t>(len, d.size() - p - 8);
+        if (memcmp(d.data() + p, "fmt ", 4) == 0 && avail >= 16) {
+            uint16_t ch; uint32_t sr; memcpy(&ch, body + 2, 2); memcpy(&sr, body + 4, 4);
+            a.channels = ch; a.sample_rate = sr; have_fmt = true;
+        } else if (memcmp(d.data() + p, "data", 4) == 0) {
+            if (!have_fmt) throw std::runtime_error("data chunk before fmt chunk");
+            a.samples.resize(avail / 2);
+            for (size_t i = 0; i < a.samples.size(); i++) { int16_t v; memcpy(&v, body + 2 * i, 2); a.samples[i] = (float)v / 32768.0f; }
+            return a;
+        }
+        p += 8 + (size_t)len + (len & 1);
+    }
+    throw std::runtime_error("no data chunk found");
+}
+
 TtsEngine TtsEngine::new_(const std::string& model_dir, const std::string& quant, Tokenizer tok) {
     TtsEngine t;
     q3tts_engine_params p;
@@ -193,6 +253,34 @@ AudioSample TtsEngine::generate_with_voice_ids(const std::vector<int32_t>& text_
     out.samples.resize((size_t)r.n_pcm);
     if (codes_out) codes_out->assign(codes.begin(), codes.begin() + (size_t)r.n_frames * 16);
     return out; // AudioSample{samples, 24000, 1}: engine.rs:651-655
+}
+
+AudioSample TtsEngine::generate_ids(const std::vector<int32_t>& text_ids, const std::string& ref_audio_path, const std::vector<int32_t>& ref_text_ids,
+                                    const std::vector<int32_t>* ins, std::vector<int32_t>* codes_out) {
+    // process_reference, engine.rs:275-301
+    std::string cache_path = ref_audio_path;
+    const size_t slash = cache_path.find_last_of('/'), dot = cache_path.find_last_of('.');
+    if (dot != std::string::npos && (slash == std::string::npos || dot > slash)) cache_path.resize(dot);
+    cache_path += ".cache"; // Path::with_extension("cache")
+    VoiceFile v;
+    bool hit = false;
+    if (FILE* f = fopen(cache_path.c_str(), "rb")) {
+        fclose(f);
+        try { cache::load_cache(cache_path, v.audio_codes, v.speaker_embedding); hit = true; } catch (...) {} // `if let Ok(..)`: a bad cache falls through
+    }
+    if (!hit) {
+        try { (void)AudioSample::load_wav(ref_audio_path); } catch (const std::exception& e) { throw std::runtime_error(std::string("Failed to load audio: ") + e.what()); }
+        throw std::runtime_error("AudioEncoder not loaded (required for processing raw audio)"); // :288-290; encoders are SURVEY rows a17 / f-2
+    }
+    if (v.speaker_embedding.size() != 2048) throw std::runtime_error("cached speaker embedding must have 2048 values");
+    return generate_with_voice_ids(text_ids, v, ins, &ref_text_ids, codes_out);
+}
+AudioSample TtsEngine::generate(const std::string& text, const std::string& ref_audio_path, const std::string& ref_text,
+                                const std::optional<std::string>& instruct) {
+    if (!tok_) throw std::runtime_error("no tokenizer attached (SURVEY row f-3): use generate_ids");
+    std::vector<int32_t> ins;
+    if (instruct) ins = tok_(*instruct);
+    return generate_ids(tok_(text), ref_audio_path, tok_(ref_text), instruct ? &ins : nullptr);
 }
 
 AudioSample TtsEngine::generate_with_voice_ids_stream(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const ChunkFn& on_chunk,

@@ -28,8 +28,16 @@ struct VoiceFile { // voice_file.rs:5-22
     void save(const std::string& path) const;
 };
 
+// ".cache" files next to reference audio (utils/cache.rs:5-67): "TTSC", u32 version 1, u64 n + n x i64 codes, u64 m + m x f32 embedding,
+// little endian.  Errors carry the reference's messages ("Invalid magic bytes", "Unsupported version").
+namespace cache {
+void save_cache(const std::string& path, const std::vector<int64_t>& codes, const std::vector<float>& emb);
+void load_cache(const std::string& path, std::vector<int64_t>& codes, std::vector<float>& emb);
+}
+
 struct AudioSample { // audio.rs:4-46
     std::vector<float> samples; uint32_t sample_rate = 24000; uint16_t channels = 1;
+    static AudioSample load_wav(const std::string& path); // audio.rs:11-23: samples read as i16 / 32768, channel count kept but not de-interleaved
     void save_wav(const std::string& path) const;
     float duration() const { return (float)samples.size() / (float)sample_rate; }
 };
@@ -53,6 +61,12 @@ public:
     AudioSample generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice,
                                         const std::vector<int32_t>* instruct_ids = nullptr, const std::vector<int32_t>* ref_text_ids = nullptr,
                                         std::vector<int32_t>* codes_out = nullptr);
+    // generate -- engine.rs:243-271: voice cloning from reference audio.  process_reference (:275-301) takes the codes + speaker
+    // embedding from "<audio>.cache" when that file exists; otherwise it needs the ONNX encoders and fails with the reference's message.
+    AudioSample generate_ids(const std::vector<int32_t>& text_ids, const std::string& ref_audio_path, const std::vector<int32_t>& ref_text_ids,
+                             const std::vector<int32_t>* instruct_ids = nullptr, std::vector<int32_t>* codes_out = nullptr);
+    AudioSample generate(const std::string& text, const std::string& ref_audio_path, const std::string& ref_text,
+                         const std::optional<std::string>& instruct = std::nullopt);
     // Streaming form (the reference keeps its `stream_tx` private and always None, engine.rs:442; SURVEY row f-4 asks for a public
     // one): on_chunk receives every decoded chunk (4 frames = 7680 samples, fewer for the tail) as soon as the codec has produced it.
     using ChunkFn = std::function<void(const float* pcm, size_t n_samples)>;

@@ -21,6 +21,7 @@ int main(int argc, char** argv) {
         for (int i = 0; i < 8; i++) ids.push_back(100 + i);
         std::vector<int32_t> codes, codes2, codes3;
         AudioSample a = eng.generate_with_voice_ids(ids, v, nullptr, nullptr, &codes);
+        a.save_wav(argv[3]);
         size_t n_chunks = 0, streamed = 0;
         AudioSample b = eng.generate_with_voice_ids_stream(ids, v, [&](const float*, size_t n) { n_chunks++; streamed += n; }, nullptr, nullptr, &codes2);
         if (codes != codes2 || a.samples != b.samples || streamed != b.samples.size() || n_chunks < 2) throw std::runtime_error("streaming result differs");
@@ -29,9 +30,16 @@ int main(int argc, char** argv) {
         std::vector<int32_t> ref_text = {7, 8, 9};
         sc.temperature = 0.7f; eng.set_sampler_config(sc);                  // sampled, seeded
         AudioSample c = eng.generate_with_voice_ids(ids, clone, nullptr, &ref_text, &codes3);
+        // generate (engine.rs:243-271) through process_reference's ".cache" short-cut (:276-281): same result as the clone VoiceFile path
+        const std::string ref_wav = std::string(argv[3]) + ".ref.wav", ref_cache = std::string(argv[3]) + ".ref.cache";
+        cache::save_cache(ref_cache, clone.audio_codes, clone.speaker_embedding);
+        std::vector<int32_t> codes4;
+        AudioSample d = eng.generate_ids(ids, ref_wav, ref_text, nullptr, &codes4);
+        if (codes4 != codes3 || d.samples != c.samples) throw std::runtime_error("cache-backed generate differs from the clone VoiceFile path");
+        try { eng.generate_ids(ids, std::string(argv[3]), ref_text); throw std::runtime_error("generate without cache or encoders should fail"); }
+        catch (const std::runtime_error& e) { if (std::string(e.what()).find("AudioEncoder not loaded (required for processing raw audio)") == std::string::npos) throw; }
         try { eng.create_voice_file("x.wav", "hello"); throw std::runtime_error("create_voice_file should fail"); }
         catch (const std::runtime_error& e) { if (std::string(e.what()).find("AudioEncoder not loaded") == std::string::npos) throw; }
-        a.save_wav(argv[3]);
         printf("PRESET");
         for (int32_t x : codes) printf(" %d", x);
         printf("\nCLONE");
