@@ -348,6 +348,7 @@ __global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrow
 // =====================================================================================================
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
+typedef float f32x2v __attribute__((ext_vector_type(2)));
 // The workgroup keeps its weight tile (32 rows x one super-segment) in registers and loops over 32-token tiles
 // (tile = blockIdx.z, += gridDim.z), so weights are streamed once per launch when gridDim.z = 1.
 // GU = gate/up form for K <= 2048: pass 0 runs the 32 gate rows over the workgroup's tiles and parks the sums in LDS, pass 1
@@ -358,7 +359,7 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                                                       int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ float red[8][32][33];
-    __shared__ __attribute__((aligned(16))) uint16_t sc_s[8][2][8][16]; // [wave][lane half][block][accumulator reg]: f16 activation scales
+    __shared__ __attribute__((aligned(16))) float sc_s[8][2][8][16]; // [wave][lane half][block][accumulator reg]: activation scales, widened to f32 once
     __shared__ float gate_s[GU ? 4 : 1][GU ? 1024 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -391,38 +392,45 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                 if (t > ntok - 1) t = ntok - 1;
                 const uint2 v = *reinterpret_cast<const uint2*>(xd + (size_t)t * nb + seg * 8 + 4 * half);
                 const int th = (r >> 2) & 1, tg = (r & 3) + 4 * (r >> 3); // token r sits in C row (reg tg, lane half th)
-                sc_s[wave][th][4 * half + 0][tg] = (uint16_t)(v.x & 0xFFFFu); sc_s[wave][th][4 * half + 1][tg] = (uint16_t)(v.x >> 16);
-                sc_s[wave][th][4 * half + 2][tg] = (uint16_t)(v.y & 0xFFFFu); sc_s[wave][th][4 * half + 3][tg] = (uint16_t)(v.y >> 16);
+                sc_s[wave][th][4 * half + 0][tg] = h2f(v.x & 0xFFFFu); sc_s[wave][th][4 * half + 1][tg] = h2f(v.x >> 16);
+                sc_s[wave][th][4 * half + 2][tg] = h2f(v.y & 0xFFFFu); sc_s[wave][th][4 * half + 3][tg] = h2f(v.y >> 16);
             }
             __syncthreads();
             if (active) {
-                i32x4v av[8];
                 int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
                 if (atok > ntok - 1) atok = ntok - 1;
                 const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
-#pragma unroll
-                for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + i * 32);
                 // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
-                float acc[16];
+                // the scale chain runs on register pairs so it can issue as v_pk_mul_f32 / v_pk_fma_f32 (IEEE per component, same bits)
+                f32x2v acc2[8];
 #pragma unroll
-                for (int g = 0; g < 16; g++) acc[g] = 0.0f;
+                for (int g = 0; g < 8; g++) acc2[g] = f32x2v{0.0f, 0.0f};
 #pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    i32x16 c;
+                for (int ih = 0; ih < 2; ih++) { // activations of 4 blocks at a time: keeps the kernel under 128 VGPRs without spilling
+                    i32x4v av[4];
 #pragma unroll
-                    for (int g = 0; g < 16; g++) c[g] = 0;
-                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
-                    const float dwf = h2f(half_of(dwv, i));
-                    const uint4 s0 = *reinterpret_cast<const uint4*>(&sc_s[wave][half][i][0]);
-                    const uint4 s1 = *reinterpret_cast<const uint4*>(&sc_s[wave][half][i][8]);
+                    for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + (4 * ih + i) * 32);
 #pragma unroll
-                    for (int g = 0; g < 16; g++) {
-                        const float sc = dwf * h2f(half_of(g < 8 ? s0 : s1, g & 7));
-                        acc[g] = q3_fmaf((float)c[g], sc, acc[g]);
+                    for (int i4 = 0; i4 < 4; i4++) {
+                        const int i = 4 * ih + i4;
+                        i32x16 c;
+#pragma unroll
+                        for (int g = 0; g < 16; g++) c[g] = 0;
+                        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i4], wv[i], c, 0, 0, 0);
+                        const float dwf = h2f(half_of(dwv, i));
+                        const f32x2v dw2 = f32x2v{dwf, dwf};
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; g4++) {
+                            const float4 sx = *reinterpret_cast<const float4*>(&sc_s[wave][half][i][4 * g4]);
+                            const f32x2v sc_a = dw2 * f32x2v{sx.x, sx.y}, sc_b = dw2 * f32x2v{sx.z, sx.w};
+                            const f32x2v ca = f32x2v{(float)c[4 * g4], (float)c[4 * g4 + 1]}, cb = f32x2v{(float)c[4 * g4 + 2], (float)c[4 * g4 + 3]};
+                            acc2[2 * g4] = __builtin_elementwise_fma(ca, sc_a, acc2[2 * g4]);
+                            acc2[2 * g4 + 1] = __builtin_elementwise_fma(cb, sc_b, acc2[2 * g4 + 1]);
+                        }
                     }
                 }
 #pragma unroll
-                for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
+                for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc2[g >> 1][g & 1];
             }
             __syncthreads();
             for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
