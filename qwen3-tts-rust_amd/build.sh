@@ -6,16 +6,21 @@ ARCH=${Q3_ARCH:-gfx950}
 FLAGS="-O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
 mkdir -p build
 OBJS=""
+PIDS=""
 for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/llama_shim.cpp; do
   [ -f "$f" ] || continue
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then
     echo "hipcc $f"
+    rm -f "$o"   # a failed compile must not leave a stale object behind for the link
     /opt/rocm/bin/hipcc $FLAGS -x hip -c "$f" -o "$o" &
+    PIDS="$PIDS $!"
   fi
   OBJS="$OBJS $o"
 done
-wait
+FAIL=0
+for p in $PIDS; do wait "$p" || FAIL=1; done
+if [ "$FAIL" != 0 ]; then echo "build failed" >&2; exit 1; fi
 /opt/rocm/bin/hipcc -shared -fPIC --offload-arch=$ARCH -o libq3tts.so $OBJS
 mkdir -p runtime && cp -f libq3tts.so runtime/libllama.so
 # host side: C++ mirror of the reference API + the Boundary-A replay harness (plain g++, no HIP)

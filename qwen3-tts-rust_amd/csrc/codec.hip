@@ -453,31 +453,31 @@ __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ d
     const int c = (int)(i % C), r = (int)(i / C);
     dst[map_row(dm, r) * C + c] = src[i];
 }
-// streaming state: history rows of segment g <-> the owning stream's slot in the per-conv state store [n_streams][H][C]
-__global__ void k_hist_load(float* __restrict__ ext, const float* __restrict__ hist, const int64_t* __restrict__ meta, int H, int C, int T) {
+// all convolutions' histories in one launch (blockIdx.z = conv): a pass loads every history up front and saves every one at the end
+struct HistDesc { float* work; float* hist; int H, C, T, pad; };
+struct HistTable { HistDesc d[48]; int n; };
+__global__ void k_hist_all(HistTable tab, const int64_t* __restrict__ meta, int save) {
+    const HistDesc e = tab.d[blockIdx.z];
     const int g = blockIdx.y;
-    const size_t n = (size_t)H * C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)e.H * e.C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= n) return;
-    ext[(size_t)g * (H + T) * C + i] = hist[(size_t)meta[g] * n + i];
+    float* w = e.work + (size_t)g * (e.H + e.T) * e.C;
+    float* h = e.hist + (size_t)meta[g] * n;
+    if (save) h[i] = w[(size_t)e.T * e.C + i]; // the last H rows of (history + new rows) become the next call's history
+    else w[i] = h[i];
 }
-__global__ void k_hist_save(const float* __restrict__ ext, float* __restrict__ hist, const int64_t* __restrict__ meta, int H, int C, int T) {
-    const int g = blockIdx.y; // the last H rows of (history + new rows) become the next call's history
-    const size_t n = (size_t)H * C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    hist[(size_t)meta[g] * n + i] = ext[((size_t)g * (H + T) + T) * C + i];
-}
-// final conv (cout = 1): out[t] = clamp(b + sum_{j,c} w[j*C+c] * in_ext[t+j][c])
-__global__ void __launch_bounds__(256) k_conv_out(const float* __restrict__ in_ext, int C, const float* __restrict__ w, float bias,
-                                                  float* __restrict__ pcm, int n, RowMap im) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+// final conv (cout = 1): one wave per output sample, lanes split the 7*C products (coalesced rows), butterfly sum, clamp
+__global__ void __launch_bounds__(256) k_conv_out_wave(const float* __restrict__ in_ext, int C, const float* __restrict__ w, float bias,
+                                                       float* __restrict__ pcm, int n, RowMap im) {
+    const int t = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (t >= n) return;
-    const size_t r0 = map_row(im, t);
-    float a = bias;
-    for (int j = 0; j < 7; j++)
-        for (int c = 0; c < C; c++) a += w[j * C + c] * in_ext[(r0 + j) * C + c];
-    pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+    const float* row = in_ext + map_row(im, t) * C; // 7 consecutive rows of C floats = one contiguous span of 7*C
+    float a = 0.0f;
+    for (int i = lane; i < 7 * C; i += 64) a += w[i] * row[i];
+    for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+    a += bias;
+    if (lane == 0) pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
 }
-
 // ---------------- host side ----------------
 struct ConvW { DevBuf<float> w, b; DevBuf<_Float16> wh, wl; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
 struct Snake { DevBuf<float> ea, inv_eb; int C = 0; };
@@ -591,16 +591,20 @@ struct CodecDecoder::Impl {
         if (sn) { g.snake_ea = sn->ea.p; g.snake_ib = sn->inv_eb.p; }
         gemm(st, g, S->splitk_ws.p, S->splitk_ws.n, c.wh.n ? c.wh.p : nullptr, c.wl.n ? c.wl.p : nullptr);
     }
-    void load_hist(hipStream_t st, const Ext& e, int G, int T, const int64_t* meta) {
+    // histories are moved by two launches per pass (k_hist_all): decode_group_async registers every conv it is about to run with
+    // the row count of this call, loads all histories before the first kernel and saves them after the last
+    HistTable table;
+    void plan_hist(const Ext& e, int T) {
         if (e.H == 0) return;
-        const size_t n = (size_t)e.H * e.C;
-        hipLaunchKernelGGL(k_hist_load, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, st, work(e), e.hist.p, meta, e.H, e.C, T);
+        Q3_CHECK(table.n < 48, "too many streaming convolutions");
+        table.d[table.n++] = HistDesc{work(e), e.hist.p, e.H, e.C, T, 0};
     }
-    void save_hist(hipStream_t st, Ext& e, int G, int T, const int64_t* meta) {
-        if (e.H == 0) return;
-        const size_t n = (size_t)e.H * e.C;
-        hipLaunchKernelGGL(k_hist_save, dim3((unsigned)((n + 255) / 256), G), dim3(256), 0, st, work(e), e.hist.p, meta, e.H, e.C, T);
+    void move_hist(hipStream_t st, int G, const int64_t* meta, bool save) {
+        size_t mx = 0;
+        for (int i = 0; i < table.n; i++) mx = std::max(mx, (size_t)table.d[i].H * table.d[i].C);
+        hipLaunchKernelGGL(k_hist_all, dim3((unsigned)((mx + 255) / 256), G, table.n), dim3(256), 0, st, table, meta, save ? 1 : 0);
     }
+
     void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int rows, RowMap dm) {
         const size_t n = (size_t)rows * s.C;
         hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n, dm);
@@ -807,17 +811,29 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
     Q3_HIP(hipMemcpyAsync(m.S->d_in.p, hin, (ncodes + 3 * (size_t)G) * 8, hipMemcpyHostToDevice, st));
     const int64_t* d_codes = m.S->d_in.p;
     const int64_t* meta = m.S->d_in.p + ncodes;
+    {   // every streaming conv of the pass with its row count per stream
+        m.table.n = 0;
+        m.plan_hist(m.z_ext, T0);
+        for (int l = 0; l < m.n_layers; l++) { m.plan_hist(m.k_ext[l], T0); m.plan_hist(m.v_ext[l], T0); }
+        int Tp = T0;
+        for (int i = 0; i < m.n_up; i++) { Tp *= m.up_ratios[i]; m.plan_hist(m.dw_ext[i], Tp); }
+        m.plan_hist(m.convin_ext, Tp);
+        for (int b = 0; b < m.n_dec; b++) {
+            m.plan_hist(m.ct_ext[b], Tp);
+            Tp *= m.dec_rates[b];
+            for (int u = 0; u < 3; u++) m.plan_hist(m.ru_ext[b][u], Tp);
+        }
+        m.plan_hist(m.out_ext, Tp);
+        m.move_hist(st, G, meta, false);
+    }
     // 1. RVQ sum -> z_ext current rows ; 2. pre_conv
-    m.load_hist(st, m.z_ext, G, T0, meta);
     hipLaunchKernelGGL(k_rvq_sum, dim3((m.cb_dim + 255) / 256, R0), dim3(256), 0, st, d_codes, m.d_cb_ptrs.p, m.n_q, m.cb_size, m.cb_dim,
                        m.work(m.z_ext), m.cb_dim, m.cur_map(m.z_ext, T0));
     m.run_conv(st, m.pre_conv, m.ext_base(m.z_ext, T0), m.cb_dim, R0, m.plain(m.S->h.p), H, H);
-    m.save_hist(st, m.z_ext, G, T0, meta);
     // 3. transformer
     for (int l = 0; l < m.n_layers; l++) {
         auto& L = m.tf[l];
         Ext &ke = m.k_ext[l], &ve = m.v_ext[l];
-        m.load_hist(st, ke, G, T0, meta); m.load_hist(st, ve, G, T0, meta);
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(R0), dim3(256), 0, st, m.S->h.p, H, L.attn_norm.p, H, m.eps, m.S->xn.p, H);
         m.run_conv(st, L.wqkv, m.plain(m.S->xn.p), H, R0, m.plain(m.S->qkv.p), 3 * H, 3 * H);
         hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
@@ -830,7 +846,6 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
         m.run_conv(st, L.wgu, m.plain(m.S->xn.p), H, R0, m.plain(m.S->gu.p), 2 * m.ffn, 2 * m.ffn);
         hipLaunchKernelGGL(k_swiglu_rows, dim3((m.ffn + 255) / 256, R0), dim3(256), 0, st, m.S->gu.p, m.ffn, m.S->act.p);
         m.run_conv(st, L.wdown, m.plain(m.S->act.p), m.ffn, R0, m.plain(m.S->h.p), H, H, EPI_RES_SCALE, m.plain(m.S->h.p), H, L.ls_ffn.p);
-        m.save_hist(st, ke, G, T0, meta); m.save_hist(st, ve, G, T0, meta); // the last window-1 positions stay as history
     }
     for (int g = 0; g < G; g++) {
         const int s = streams[g], tot = m.kv_len[s] + T0;
@@ -846,7 +861,6 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
         auto& U = m.up[i];
         const int f = m.up_ratios[i];
         Ext& e = m.dw_ext[i];
-        m.load_hist(st, e, G, T * f, meta);
         // transposed conv: GEMM row (g,t) writes f consecutive H-wide rows of segment g: [T][f*H] == [T*f][H]
         m.run_conv(st, U.ct, m.plain(x), H, G * T, Impl::Loc{m.work(e) + (size_t)e.H * e.C, T, e.H}, f * H, H);
         T *= f;
@@ -856,45 +870,37 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
         m.run_conv(st, U.pw1, m.plain(m.S->t2.p), H, G * T, m.plain(m1), 4 * H, 4 * H, EPI_GELU);
         // y_new = y + gamma * (pw2(m1) + b): write into t2 (y lives in the ext buffer)
         m.run_conv(st, U.pw2, m.plain(m1), 4 * H, G * T, m.plain(m.S->t2.p), H, H, EPI_RES_SCALE, m.ext_cur(e, T), H, U.gamma.p);
-        m.save_hist(st, e, G, T, meta);
         // next stage input must not alias its own output buffers: move to t1
         m.copy_rows(st, m.S->t2.p, m.S->t1.p, G * T, H, plain_map());
         x = m.S->t1.p;
     }
     // 6. conv_in
-    m.load_hist(st, m.convin_ext, G, T, meta);
     m.copy_rows(st, x, m.work(m.convin_ext), G * T, H, m.cur_map(m.convin_ext, T));
     m.run_conv(st, m.conv_in, m.ext_base(m.convin_ext, T), H, G * T, m.plain(m.S->t1.p), m.dec_dim, m.dec_dim);
-    m.save_hist(st, m.convin_ext, G, T, meta);
     float* d = m.S->t1.p; // [G*T][ch]
     // 7. decoder blocks
     for (int b = 0; b < m.n_dec; b++) {
         auto& B = m.blk[b];
         Ext& ce = m.ct_ext[b];
-        m.load_hist(st, ce, G, T, meta);
         m.snake(st, B.snake, d, m.work(ce), G * T, m.cur_map(ce, T));
         float* y = (d == m.S->t1.p) ? m.S->t2.p : m.S->t1.p; // [G*T*r][co]
         m.run_conv(st, B.ct, m.ext_base(ce, T), B.cin, G * T, m.plain(y), B.rate * B.cout, B.cout);
-        m.save_hist(st, ce, G, T, meta);
         T *= B.rate;
         for (int u = 0; u < 3; u++) {
             Ext& re = m.ru_ext[b][u];
             auto& R = B.ru[u];
-            m.load_hist(st, re, G, T, meta);
             m.snake(st, R.s1, y, m.work(re), G * T, m.cur_map(re, T));
             float* c1o = d; // the block input buffer is free now: reuse as scratch [G*T][co]
             m.run_conv(st, R.c1, m.ext_base(re, T), B.cout, G * T, m.plain(c1o), B.cout, B.cout, EPI_SNAKE, Impl::Loc{nullptr, SEG_NONE, 0}, 0, nullptr, &R.s2); // conv1 + snake2 fused
-            m.save_hist(st, re, G, T, meta);
             m.run_conv(st, R.c2, m.plain(c1o), B.cout, G * T, m.plain(y), B.cout, B.cout, EPI_RES, m.plain(y), B.cout);
         }
         d = y;
     }
     // 8. output conv
-    m.load_hist(st, m.out_ext, G, T, meta);
     m.snake(st, m.snake_out, d, m.work(m.out_ext), G * T, m.cur_map(m.out_ext, T));
-    hipLaunchKernelGGL(k_conv_out, dim3((G * T + 255) / 256), dim3(256), 0, st, m.work(m.out_ext), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T,
+    hipLaunchKernelGGL(k_conv_out_wave, dim3((G * T + 3) / 4), dim3(256), 0, st, m.work(m.out_ext), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T,
                        m.base_map(m.out_ext, T));
-    m.save_hist(st, m.out_ext, G, T, meta);
+    m.move_hist(st, G, meta, true);
     for (int g = 0; g < G; g++) Q3_HIP(hipMemcpyAsync(pcm[g], m.S->pcm.p + (size_t)g * T, (size_t)T * 4, hipMemcpyDeviceToHost, st));
     return T;
 }
