@@ -88,7 +88,7 @@ __global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __res
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
     const int ntiles = (ntok + 31) / 32;
-    static const int target = [] { const char* e = std::getenv("Q3_MFMA_WGS"); return e ? atoi(e) : 512; }(); // measured on MI355X at 64 tokens: 128 -> 6.74, 256 -> 6.16, 512 -> 6.13 ms/step
+    static const int target = [] { const char* e = std::getenv("Q3_MFMA_WGS"); return e ? atoi(e) : 1024; }(); // measured on MI355X at 64 tokens: 128 -> 6.74, 256 -> 6.16, 512..2048 -> 6.14 ms/step (prefill 50.6 -> 48.1 ms at 1024)
     int z = (target + rowgroups * nsseg - 1) / (rowgroups * nsseg);
     return z < 1 ? 1 : (z > ntiles ? ntiles : z);
 }
