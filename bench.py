@@ -209,7 +209,7 @@ def main():
             "codec_ms_per_chunk": (st["codec_ms"] / st["codec_calls"]) if st["codec_calls"] else None,
             "frame_hbm_frac": (step_bytes / (frame_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if frame_ms > 0 else None,
             # dominant kernel by algorithmic bytes: the talker's fused gate/up kernel (26.7 MB of Q8_0 weights per launch, 28 per frame)
-            "roofline": {"bound": "hbm", "kernel": "q3::k_gateup_swiglu<1> (talker: norm + gate/up GEMV + SwiGLU + quant; %d launches)" % si["gu_launches"],
+            "roofline": {"bound": "hbm", "kernel": "q3::k_gateup_swiglu<1, 8> (talker: norm + gate/up GEMV + SwiGLU + quant; %d launches)" % si["gu_launches"],
                          "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
                          "avg_launch_us": 1e3 * si["gu_ms"] / max(si["gu_launches"], 1),
                          "bytes_per_launch": si["gu_bytes"] / max(si["gu_launches"], 1),

@@ -11,6 +11,7 @@
 // Arithmetic is include/q3tts_spec.h's, bit-identical to the unfused kernels and to oracle/.
 #include "kernels.h"
 #include "kdev.h"
+#include "q3_common.h"
 
 namespace q3 {
 
@@ -253,9 +254,11 @@ void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, co
 // D: norm prologue + gate & up GEMV + SwiGLU + int8 quant.  Workgroup = 32 gate rows + the 32 matching up
 // rows (one output quant block); wave = one segment of both (16 weight loads in flight per lane).
 // ===================================================================================================
-template <int MT>
-__global__ void __launch_bounds__(512) k_gateup_swiglu(Q8Mat w, int ff, NormPro a, int8_t* __restrict__ aq,
-                                                       uint16_t* __restrict__ ad, int ntok) {
+// NSEG (waves = 256-element segments of K; 8 = the talker's K = 2048) is a template parameter only so that profiles list the talker's
+// and the predictor's launches as different kernels: bench.py's roofline line is about k_gateup_swiglu<1, 8>.
+template <int MT, int NSEG>
+__global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, NormPro a, int8_t* __restrict__ aq,
+                                                             uint16_t* __restrict__ ad, int ntok) {
     __shared__ float red[8][2][32 * MT];
     __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
     __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
@@ -316,9 +319,15 @@ void launch_gateup_swiglu(hipStream_t st, const Q8Mat& w, int ff, const NormPro&
     const int nseg = w.K >> 8;
     const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : 4;
     dim3 grid(ff / 32, 1, (ntok + mt - 1) / mt);
-    if (mt == 1) hipLaunchKernelGGL((k_gateup_swiglu<1>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
-    else if (mt == 2) hipLaunchKernelGGL((k_gateup_swiglu<2>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
-    else hipLaunchKernelGGL((k_gateup_swiglu<4>), grid, dim3(64 * nseg), 0, st, w, ff, a, aq, ad, ntok);
+#define Q3_GU(MTV, NS) hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok)
+#define Q3_GU_NS(NS) do { if (mt == 1) Q3_GU(1, NS); else if (mt == 2) Q3_GU(2, NS); else Q3_GU(4, NS); } while (0)
+    switch (nseg) {
+        case 1: Q3_GU_NS(1); break; case 2: Q3_GU_NS(2); break; case 3: Q3_GU_NS(3); break; case 4: Q3_GU_NS(4); break;
+        case 5: Q3_GU_NS(5); break; case 6: Q3_GU_NS(6); break; case 7: Q3_GU_NS(7); break; case 8: Q3_GU_NS(8); break;
+        default: throw Error("k_gateup_swiglu: K must be at most 2048");
+    }
+#undef Q3_GU_NS
+#undef Q3_GU
 }
 
 // ===================================================================================================
