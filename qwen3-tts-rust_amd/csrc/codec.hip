@@ -292,8 +292,9 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         // measured inside the 64-stream pipeline: N = 768 (K = 5376) 96 -> 64 us with the tall tile, N <= 384 no gain
         const bool tall = g.M >= big_m && g.N >= 512 && ((g.N + 63) / 64) * ((g.M + 127) / 128) >= 160;
         const int t2 = tall ? ((g.N + 63) / 64) * ((g.M + 127) / 128) : tiles;
+        static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }(); // split-K until this many workgroups
         int ks = 1;
-        while (t2 * ks < 256 && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
+        while (t2 * ks < wg_target && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
         if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
         else hipLaunchKernelGGL((k_conv_gemm_h<1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
         if (ks > 1) {

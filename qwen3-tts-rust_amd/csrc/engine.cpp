@@ -110,7 +110,8 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     if (p.load_codec) {
         // codec streams outnumber the slots: a retired sequence's last chunks still drain while its slot is already reused
         // up to 16 streams share one decode pass; two lanes (HIP streams + scratch) let consecutive groups overlap
-        const int n_cs = B + std::min(B, 16), gmax = std::min(B, 16), n_lanes = B > 1 ? 2 : 1;
+        static const int group_cap = [] { const char* e = std::getenv("Q3_CODEC_GROUP"); return e ? atoi(e) : 16; }(); // streams per decode pass
+        const int n_cs = B + std::min(B, 16), gmax = std::max(1, std::min(B, group_cap)), n_lanes = B > 1 ? 2 : 1;
         codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes, gmax));
         st2_.resize(n_lanes);
         for (auto& s2 : st2_) Q3_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
