@@ -155,6 +155,10 @@ int q3tts_chunker_push(q3tts_chunker* c, const int64_t* codes, int32_t n, int32_
 typedef struct q3tts_decoder q3tts_decoder;
 int q3tts_decoder_create(const char* codec_gguf, int32_t n_streams, q3tts_decoder** out);
 void q3tts_decoder_destroy(q3tts_decoder* d);
+/* batched form: one pass decodes up to max_group streams that each contribute the same number of new frames */
+int q3tts_decoder_create_ex(const char* codec_gguf, int32_t n_streams, int32_t max_frames_per_call, int32_t max_group, q3tts_decoder** out);
+/* streams [G] distinct; codes [G][n_frames][16] i64; wav_out [G][n_frames*samples_per_frame] f32 */
+int q3tts_decoder_decode_group(q3tts_decoder* d, int32_t G, const int32_t* streams, const int64_t* codes, int32_t n_frames, float* wav_out);
 int q3tts_decoder_samples_per_frame(q3tts_decoder* d);
 int q3tts_decoder_reset(q3tts_decoder* d, int32_t stream);
 /* codes [n_frames][16] i64; writes up to n_frames*samples_per_frame floats; *valid_samples = prefix to keep */

@@ -10,7 +10,7 @@ struct q3tts_engine { std::unique_ptr<Engine> e; };
 struct q3tts_assets { std::unique_ptr<HostAssets> owned; const HostAssets* a = nullptr; };
 struct q3tts_sampler { Sampler s; };
 struct q3tts_chunker { std::unique_ptr<Chunker> c; };
-struct q3tts_decoder { std::unique_ptr<CodecDecoder> d; hipStream_t st = nullptr; };
+struct q3tts_decoder { std::unique_ptr<CodecDecoder> d; hipStream_t st = nullptr; float* pinned = nullptr; size_t pinned_cap = 0; };
 struct q3tts_tf { std::unique_ptr<TfContext> c; };
 
 #define Q3_API_BEGIN try {
@@ -257,7 +257,36 @@ int q3tts_decoder_create(const char* path, int32_t n_streams, q3tts_decoder** ou
     return Q3TTS_OK;
     Q3_API_END(Q3TTS_ERR)
 }
-void q3tts_decoder_destroy(q3tts_decoder* d) { if (d && d->st) (void)hipStreamDestroy(d->st); delete d; }
+int q3tts_decoder_create_ex(const char* path, int32_t n_streams, int32_t max_frames, int32_t max_group, q3tts_decoder** out) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(path && out && n_streams >= 1 && max_frames >= 1 && max_group >= 1, "bad arguments");
+    auto* h = new q3tts_decoder();
+    try { h->d.reset(new CodecDecoder(path, n_streams, max_frames, 1, max_group)); Q3_HIP(hipStreamCreate(&h->st)); } catch (...) { delete h; throw; }
+    *out = h;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_decoder_decode_group(q3tts_decoder* d, int32_t G, const int32_t* streams, const int64_t* codes, int32_t n_frames, float* wav) {
+    Q3_API_BEGIN
+    Q3_CHECK(d && streams && codes && wav && G >= 1 && n_frames >= 1, "bad arguments");
+    const size_t per = (size_t)n_frames * d->d->samples_per_frame();
+    if (d->pinned_cap < per * G) { // pinned staging for the async D2H copies of the pass
+        if (d->pinned) (void)hipHostFree(d->pinned);
+        Q3_HIP(hipHostMalloc((void**)&d->pinned, per * G * sizeof(float)));
+        d->pinned_cap = per * G;
+    }
+    std::vector<float*> dst(G);
+    for (int g = 0; g < G; g++) dst[g] = d->pinned + (size_t)g * per;
+    std::vector<int> st(streams, streams + G);
+    const int got = d->d->decode_group_async(d->st, G, st.data(), codes, n_frames, dst.data(), 0);
+    Q3_HIP(hipStreamSynchronize(d->st));
+    if (got < 0) throw Error("decode failed");
+    std::copy(d->pinned, d->pinned + per * G, wav);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+void q3tts_decoder_destroy(q3tts_decoder* d) { if (d && d->st) (void)hipStreamDestroy(d->st); if (d && d->pinned) (void)hipHostFree(d->pinned); delete d; }
 int q3tts_decoder_samples_per_frame(q3tts_decoder* d) { return d->d->samples_per_frame(); }
 int q3tts_decoder_reset(q3tts_decoder* d, int32_t stream) { Q3_API_BEGIN d->d->reset(stream); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 int q3tts_decoder_decode(q3tts_decoder* d, int32_t stream, const int64_t* codes, int32_t n_frames, int32_t is_last, float* wav, int64_t* valid) {

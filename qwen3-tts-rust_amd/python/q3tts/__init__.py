@@ -63,7 +63,7 @@ SYMBOLS = [
     "q3tts_decoder_reset", "q3tts_decoder_decode", "q3tts_mel_frames", "q3tts_mel", "q3tts_tf_open", "q3tts_tf_close",
     "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
     "q3tts_op_argmax", "q3tts_op_project", "q3tts_op_sample", "q3tts_submit", "q3tts_poll", "q3tts_fetch", "q3tts_wait",
-    "q3tts_release", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
+    "q3tts_release", "q3tts_decoder_create_ex", "q3tts_decoder_decode_group", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
 ]
 
 
@@ -116,6 +116,8 @@ def lib():
         L.q3tts_chunker_push.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.q3tts_decoder_create.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
         L.q3tts_decoder_destroy.argtypes = [C.c_void_p]
+        L.q3tts_decoder_create_ex.argtypes = [C.c_char_p, C.c_int32, C.c_int32, C.c_int32, C.POINTER(C.c_void_p)]
+        L.q3tts_decoder_decode_group.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p]
         L.q3tts_decoder_samples_per_frame.argtypes = [C.c_void_p]
         L.q3tts_decoder_reset.argtypes = [C.c_void_p, C.c_int32]
         L.q3tts_decoder_decode.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.POINTER(C.c_int64)]
@@ -416,9 +418,12 @@ class TfContext:  # LlamaModel + LlamaContext at the embedding level (llama/mod.
 
 
 class Decoder:  # AudioDecoder (onnx.rs:324-496)
-    def __init__(self, path, n_streams=1):
+    def __init__(self, path, n_streams=1, max_frames=64, max_group=1):
         h = C.c_void_p()
-        _chk(lib().q3tts_decoder_create(path.encode(), n_streams, C.byref(h)))
+        if max_group > 1 or max_frames != 64:
+            _chk(lib().q3tts_decoder_create_ex(path.encode(), n_streams, max_frames, max_group, C.byref(h)))
+        else:
+            _chk(lib().q3tts_decoder_create(path.encode(), n_streams, C.byref(h)))
         self.h = h.value
         self.spf = lib().q3tts_decoder_samples_per_frame(self.h)
 
@@ -436,6 +441,15 @@ class Decoder:  # AudioDecoder (onnx.rs:324-496)
         valid = C.c_int64(0)
         _chk(lib().q3tts_decoder_decode(self.h, stream, _p(codes), codes.shape[0], 1 if is_last else 0, _p(wav), C.byref(valid)))
         return wav[: valid.value]
+
+
+    def decode_group(self, streams, codes):
+        """codes [G][n_frames][16] for G distinct streams -> wav [G][n_frames*spf] (one decode pass for the whole group)"""
+        st = np.ascontiguousarray(streams, np.int32)
+        codes = np.ascontiguousarray(codes, np.int64).reshape(st.size, -1, 16)
+        wav = np.zeros((st.size, codes.shape[1] * self.spf), np.float32)
+        _chk(lib().q3tts_decoder_decode_group(self.h, st.size, _p(st), _p(codes), codes.shape[1], _p(wav)))
+        return wav
 
 
 def op_gemv_q8(w_raw, n, k, xq, xd, lpr=0):

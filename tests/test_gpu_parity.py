@@ -467,6 +467,24 @@ def test_codec_decoder_chunked_vs_oracle(gpu, oracle, tiny_model):
     gd.close()
 
 
+def test_codec_group_decode_vs_oracle(gpu, oracle, tiny_model):
+    """q3tts_decoder_decode_group: 5 streams with different histories decoded in one pass per chunk == the oracle stream by stream"""
+    path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
+    gd = gpu.Decoder(path, n_streams=6, max_frames=4, max_group=5)
+    rng = np.random.default_rng(8)
+    codes = rng.integers(0, 2048, (5, 12, 16))
+    streams = [4, 0, 2, 5, 1]
+    for s in streams:
+        gd.reset(s)
+    got = np.concatenate([gd.decode_group(streams, codes[:, o:o + 4]) for o in (0, 4, 8)], axis=1)
+    oc = oracle.Codec(path)
+    for i in range(5):
+        oc.reset()
+        ref = oc.decode(codes[i]).copy()
+        assert np.sqrt(np.mean((ref - got[i]) ** 2)) < PCM_RMS_TOL, i
+    oc.close(); gd.close()
+
+
 def test_mel_kernel_vs_oracle(gpu, oracle):
     """row a16: log-mel front end (onnx.rs:167-320) on the device vs the oracle; float tolerance (f32 DFT vs double FFT)."""
     rng = np.random.default_rng(12)
