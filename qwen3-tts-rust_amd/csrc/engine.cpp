@@ -71,9 +71,24 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     d_tab_rows_.alloc(16); d_tab_rows_.upload(rows.data(), 16);
     // ---- KV pools ----
     const int pages_per_seq = (p.max_prompt + p.max_steps + 1 + 63) / 64;
-    kv_t_.reset(new KvPool(talker_->hp().n_layer, talker_->hp().n_kv, B * pages_per_seq, B, pages_per_seq));
+    // talker page-table row B is the scratch sequence: idle slots of the frame graph read and write its single page, so the pages of a
+    // slot that is being prefilled (or was just recycled) are never touched by the graph
+    kv_t_.reset(new KvPool(talker_->hp().n_layer, talker_->hp().n_kv, B * pages_per_seq + 1, B + 1, pages_per_seq));
     kv_p_.reset(new KvPool(predictor_->hp().n_layer, predictor_->hp().n_kv, B, B, 1));
-    for (int b = 0; b < B; b++) { kv_p_->ensure(b, 16); kv_t_->ensure(b, 1); }
+    for (int b = 0; b < B; b++) kv_p_->ensure(b, 16);
+    kv_t_->ensure(B, 1);
+    {
+        const char* e = std::getenv("Q3_ASYNC_PREFILL");
+        async_pf_ = B > 1 && !(e && e[0] == '0');
+    }
+    if (async_pf_) {
+        talker_pf_.reset(new Transformer(dir + "/qwen3_tts_talker.gguf", Q3_TALKER_NCTX, 256));
+        Q3_HIP(hipStreamCreateWithFlags(&st_pf_, hipStreamNonBlocking));
+        Q3_HIP(hipEventCreate(&pf_done_)); Q3_HIP(hipEventCreate(&pf_e0_));
+        arena_pf_cap_ = (size_t)4096 * (Q3_EMBD * 4 + 24) + ((size_t)1 << 16); // prompts of one admission: at most 4096 rows + routing tables
+        Q3_HIP(hipHostMalloc((void**)&arena_pf_, arena_pf_cap_));
+        d_prompt_pf_.alloc((size_t)256 * Q3_EMBD); d_pfa_seq_.alloc(256); d_pfa_slot_.alloc(256); d_pfa_pos_.alloc(4 * 256);
+    }
     // ---- per-slot state ----
     hist_stride_ = p.max_steps * 16;
     tl_stride_ = (Q3_SAMPLE_END + 31) & ~31;
@@ -95,10 +110,10 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     d_pseq_.alloc(B); d_pseq_.upload(seq.data(), B);
     d_pslot_.alloc(slot.size()); d_pslot_.upload(slot.data(), slot.size());
     d_ppos_.alloc(pos.size()); d_ppos_.upload(pos.data(), pos.size());
-    d_tseq_.upload(seq.data(), B);
     h_maxf_.assign(B, 0); h_fin_.assign(B, 1); h_nfr_.assign(B, 0); h_mask_.assign(B, -1); h_nprompt_.assign(B, 0); h_topk_.assign(B, 0);
     h_temp_.assign(B, 0.0f); h_topp_.assign(B, 1.0f);
-    slot_req_.assign(B, nullptr);
+    slot_req_.assign(B, nullptr); slot_live_.assign(B, 0);
+    if (async_pf_) { d_pf_logits_.alloc((size_t)B * tl_stride_); d_pf_hidden_.alloc((size_t)B * Q3_EMBD); }
     {
         std::vector<q3_u64> k0((size_t)16 * B, pack_key(-INFINITY, 0)), n0(B, pack_key(-INFINITY, 0));
         d_keys_.upload(k0.data(), k0.size()); d_next_key0_.upload(n0.data(), n0.size());
@@ -173,6 +188,10 @@ Engine::~Engine() {
     }
     if (pcm_pinned_) (void)hipHostFree(pcm_pinned_);
     if (arena_) (void)hipHostFree(arena_);
+    if (arena_pf_) (void)hipHostFree(arena_pf_);
+    if (pf_done_) (void)hipEventDestroy(pf_done_);
+    if (pf_e0_) (void)hipEventDestroy(pf_e0_);
+    if (st_pf_) (void)hipStreamDestroy(st_pf_);
     for (auto s2 : st2_) (void)hipStreamDestroy(s2);
     if (st_) (void)hipStreamDestroy(st_);
 }
@@ -259,10 +278,11 @@ Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {
 
 void Engine::upload_slot_state() {
     const int W = B_;
-    std::vector<int32_t> tslot(W, 0), tpos((size_t)4 * W, 0);
+    std::vector<int32_t> tslot(W, 0), tpos((size_t)4 * W, 0), tseq(W, W); // idle slots step on the scratch sequence (row W)
     for (int b = 0; b < W; b++) {
-        if (!slot_req_.empty() && slot_req_[b]) { const int t = h_nprompt_[b] + h_nfr_[b]; tslot[b] = t; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = t; }
+        if (!slot_live_.empty() && slot_live_[b]) { const int t = h_nprompt_[b] + h_nfr_[b]; tslot[b] = t; tpos[4 * b] = tpos[4 * b + 1] = tpos[4 * b + 2] = t; tseq[b] = b; }
     }
+    h2d(d_tseq_.p, tseq.data(), (size_t)W * 4);
     h2d(d_maxframes_.p, h_maxf_.data(), (size_t)W * 4); h2d(d_finished_.p, h_fin_.data(), (size_t)W * 4); h2d(d_nframes_.p, h_nfr_.data(), (size_t)W * 4);
     h2d(d_tslot_.p, tslot.data(), (size_t)W * 4); h2d(d_tpos_.p, tpos.data(), (size_t)16 * W); h2d(d_maskeos_.p, h_mask_.data(), (size_t)W * 4);
     h2d(d_temp_.p, h_temp_.data(), (size_t)W * 4); h2d(d_topk_.p, h_topk_.data(), (size_t)W * 4); h2d(d_topp_.p, h_topp_.data(), (size_t)W * 4);
@@ -451,18 +471,23 @@ int64_t Engine::submit(const GenRequest& g, bool want_pcm, bool copy_prompt) {
     return raw->id;
 }
 
-// moves queued requests into free slots (lowest slot first, so the active slots stay packed and a narrow graph suffices)
+// moves queued requests into free slots (lowest slot first, so the live slots stay packed and a narrow graph suffices)
 void Engine::admit() {
+    if (async_pf_ && !pf_batch_.empty()) return; // one admission wave in flight at a time
     std::vector<Req*> batch;
     {
         std::lock_guard<std::mutex> lk(mu_);
-        // a prefill stalls every running sequence for its duration, so under load admissions are grouped: wait until an eighth of
-        // the slots is free -- unless the engine is idle or the free slots already cover the whole queue
-        const int free_slots = B_ - n_active_, quantum = std::max(1, B_ / 8);
+        // admissions are grouped under load: wait until an eighth of the slots is free -- unless the engine is idle or the free slots
+        // already cover the whole queue (a synchronous prefill stalls every running sequence; an asynchronous one still shares the GPU)
+        int reserved = 0;
+        for (int b = 0; b < B_; b++) if (slot_req_[b]) reserved++;
+        const int free_slots = B_ - reserved, quantum = std::max(1, B_ / 8);
         if (free_slots < quantum && n_active_ > 0 && free_slots < (int)pending_.size()) return;
-        while (!pending_.empty() && n_active_ < B_) {
+        size_t rows = 0;
+        while (!pending_.empty() && reserved < B_) {
             Req* r = pending_.front();
             if (r->want_pcm && cs_free_.empty()) break; // every codec stream still drains: admit after the next harvest
+            if (async_pf_ && !batch.empty() && rows + (size_t)r->r.n_prompt > 4096) break; // staging arena of one wave
             int slot = -1;
             for (int b = 0; b < B_; b++) if (!slot_req_[b]) { slot = b; break; }
             if (slot < 0) break;
@@ -470,31 +495,13 @@ void Engine::admit() {
             r->slot = slot;
             if (r->want_pcm) { r->cs = cs_free_.back(); cs_free_.pop_back(); }
             r->state = REQ_RUNNING; r->t_admit = now_ms();
-            slot_req_[slot] = r; n_active_++;
+            slot_req_[slot] = r; reserved++;
+            rows += (size_t)r->r.n_prompt;
             batch.push_back(r);
         }
     }
     if (batch.empty()) return;
-    arena_used_ = 0; // st_ is idle between scheduler operations
-    bool sampled = false;
-    for (int b = 0; b < B_; b++) if (slot_req_[b] && slot_req_[b]->r.sampler.temperature > 0.0f) sampled = true;
-    const q3_u64 armed[17] = {pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
-                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
-                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
-                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0)};
-    const uint32_t zero = 0;
     for (Req* r : batch) {
-        const int b = r->slot;
-        kv_t_->release(b);
-        kv_t_->ensure(b, r->r.n_prompt + r->r.max_steps + 1, st_);
-        h_maxf_[b] = r->r.max_steps; h_fin_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = r->r.n_prompt;
-        h_mask_[b] = r->r.mask_eos ? Q3_CODEC_EOS : -1;
-        h_temp_[b] = r->r.sampler.temperature; h_topk_[b] = r->r.sampler.top_k; h_topp_[b] = r->r.sampler.top_p;
-        StdRng rng(r->seed); // llama/mod.rs:648: the device regenerates this ChaCha12 stream from the key and a draw counter
-        h2d(d_rngkey_.p + (size_t)b * 8, rng.key(), 32);
-        h2d(d_draws_.p + b, &zero, 4);
-        h2d(d_keys_.p + (size_t)b * 16, armed, 16 * 8);
-        h2d(d_next_key0_.p + b, armed, 8);
         if (r->want_pcm) { // the decoder thread clears the codec stream's state right before the request's first chunk
             { std::lock_guard<std::mutex> lk(dmu_); dq_.push_back(DecTask{r, {}, false, false, true}); }
             dcv_.notify_all();
@@ -506,9 +513,17 @@ void Engine::admit() {
         }));
         Q3_HIP(hipEventCreate(&r->ev_admit));
     }
-    upload_slot_state();
+    if (async_pf_) { prefill_async(batch); return; }
+    // ---- synchronous form (single-slot engines: lowest latency, nothing else is running) ----
+    arena_used_ = 0; // st_ is idle between scheduler operations
+    for (Req* r : batch) kv_t_->release(r->slot), kv_t_->ensure(r->slot, r->r.n_prompt + r->r.max_steps + 1, st_);
+    pf_batch_ = batch;
+    bool sampled = false;
+    for (Req* r : batch) if (r->r.sampler.temperature > 0.0f) sampled = true;
+    for (int b = 0; b < B_; b++) if (slot_live_[b] && slot_req_[b]->r.sampler.temperature > 0.0f) sampled = true;
     hipEvent_t e0, e1;
     Q3_HIP(hipEventCreate(&e0)); Q3_HIP(hipEventCreate(&e1));
+    activate(); // slot state first: the prefill heads write code_0 / hidden straight into the live arrays
     Q3_HIP(hipEventRecord(e0, st_));
     for (Req* r : batch) Q3_HIP(hipEventRecord(r->ev_admit, st_)); // the AR stream is idle here: marks "admitted"
     prefill(batch, sampled);
@@ -521,12 +536,110 @@ void Engine::admit() {
     for (Req* r : batch) r->prefill_ms = t - r->t_submit;
 }
 
+// Prefill of one admission wave on the second talker instance / stream: every chunk is enqueued without host waits (the prompts of
+// the wave sit in their own pinned arena); each sequence's last token leaves its logits row and hidden row in staging buffers.
+void Engine::prefill_async(const std::vector<Req*>& batch) {
+    size_t total = 0;
+    for (Req* r : batch) {
+        total += (size_t)r->r.n_prompt;
+        kv_t_->release(r->slot);
+        kv_t_->ensure(r->slot, r->r.n_prompt + r->r.max_steps + 1, st_pf_);
+    }
+    const int chunk = talker_pf_->max_tok();
+    unsigned char* cur = arena_pf_;
+    size_t bi = 0; int t = 0, done_tok = 0;
+    Q3_HIP(hipEventRecord(pf_e0_, st_pf_));
+    for (Req* r : batch) Q3_HIP(hipEventRecord(r->ev_admit, st_pf_));
+    talker_pf_->set_same_seq_tokens(true);
+    while ((size_t)done_tok < total) {
+        const int n_max = (int)std::min<size_t>(total - done_tok, (size_t)chunk);
+        float* stage = (float*)cur; cur += (size_t)n_max * Q3_EMBD * 4;
+        int32_t* seq = (int32_t*)cur; cur += (size_t)n_max * 4;
+        int32_t* slot = (int32_t*)cur; cur += (size_t)n_max * 4;
+        int32_t* pos = (int32_t*)cur; cur += (size_t)n_max * 16;
+        Q3_CHECK((size_t)(cur - arena_pf_) <= arena_pf_cap_, "prefill staging arena overflow");
+        int n = 0;
+        std::vector<std::pair<Req*, int>> lasts;
+        while (n < n_max && bi < batch.size()) {
+            Req* r = batch[bi];
+            std::copy(r->r.prompt + (size_t)t * Q3_EMBD, r->r.prompt + (size_t)(t + 1) * Q3_EMBD, stage + (size_t)n * Q3_EMBD);
+            seq[n] = r->slot; slot[n] = t; pos[4 * n] = pos[4 * n + 1] = pos[4 * n + 2] = t; pos[4 * n + 3] = 0; // engine.rs:306-314
+            if (t == r->r.n_prompt - 1) { lasts.emplace_back(r, n); bi++; t = 0; } else t++;
+            n++;
+        }
+        Q3_HIP(hipMemcpyAsync(d_prompt_pf_.p, stage, (size_t)n * Q3_EMBD * 4, hipMemcpyHostToDevice, st_pf_));
+        Q3_HIP(hipMemcpyAsync(d_pfa_seq_.p, seq, (size_t)n * 4, hipMemcpyHostToDevice, st_pf_));
+        Q3_HIP(hipMemcpyAsync(d_pfa_slot_.p, slot, (size_t)n * 4, hipMemcpyHostToDevice, st_pf_));
+        Q3_HIP(hipMemcpyAsync(d_pfa_pos_.p, pos, (size_t)n * 16, hipMemcpyHostToDevice, st_pf_));
+        TokMeta tm{d_pfa_seq_.p, d_pfa_slot_.p, d_pfa_pos_.p};
+        Transformer::Input in; in.x = d_prompt_pf_.p; in.x_stride = Q3_EMBD;
+        talker_pf_->forward(st_pf_, in, n, tm, kv_t_->view(), nullptr);
+        for (auto& lb : lasts) { // logits + hidden of the LAST prompt token (engine.rs:550-554,565-566); code_0 is drawn at activation
+            const int sb = lb.first->slot;
+            talker_pf_->head(st_pf_, lb.second, 1, 0, tl_stride_, d_pf_logits_.p + (size_t)sb * tl_stride_, tl_stride_, nullptr, -1, d_pf_hidden_.p + (size_t)sb * Q3_EMBD);
+        }
+        done_tok += n;
+    }
+    Q3_HIP(hipEventRecord(pf_done_, st_pf_));
+    pf_batch_ = batch;
+    n_prefilling_ = (int)batch.size();
+}
+
+// The admission wave joins the frame graph: slot state (positions, sampler parameters, RNG stream, frame counters) goes live, and --
+// asynchronous form -- the staged hidden row is copied in and code_0 of the first frame is drawn from the staged logits with the
+// slot's own sampler state (greedy slots take the sampler kernel's first-max branch).  Runs on st_ between two frame groups.
+void Engine::activate() {
+    if (pf_batch_.empty()) return;
+    std::vector<Req*> batch;
+    batch.swap(pf_batch_);
+    arena_used_ = 0; // st_ is idle between scheduler operations
+    const q3_u64 armed[17] = {pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0), pack_key(-INFINITY, 0),
+                              pack_key(-INFINITY, 0), pack_key(-INFINITY, 0)};
+    const uint32_t zero = 0;
+    for (Req* r : batch) {
+        const int b = r->slot;
+        h_maxf_[b] = r->r.max_steps; h_fin_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = r->r.n_prompt;
+        h_mask_[b] = r->r.mask_eos ? Q3_CODEC_EOS : -1;
+        h_temp_[b] = r->r.sampler.temperature; h_topk_[b] = r->r.sampler.top_k; h_topp_[b] = r->r.sampler.top_p;
+        StdRng rng(r->seed); // llama/mod.rs:648: the device regenerates this ChaCha12 stream from the key and a draw counter
+        h2d(d_rngkey_.p + (size_t)b * 8, rng.key(), 32);
+        h2d(d_draws_.p + b, &zero, 4);
+        h2d(d_keys_.p + (size_t)b * 16, armed, 16 * 8);
+        h2d(d_next_key0_.p + b, armed, 8);
+        slot_live_[b] = 1;
+    }
+    upload_slot_state();
+    if (async_pf_) {
+        float ms = 0;
+        Q3_HIP(hipEventElapsedTime(&ms, pf_e0_, pf_done_));
+        stats.prefill_ms += ms;
+        for (Req* r : batch) {
+            const int b = r->slot;
+            Q3_HIP(hipMemcpyAsync(d_thidden_.p + (size_t)b * Q3_EMBD, d_pf_hidden_.p + (size_t)b * Q3_EMBD, (size_t)Q3_EMBD * 4, hipMemcpyDeviceToDevice, st_));
+            SampleArgs sa{d_pf_logits_.p + (size_t)b * tl_stride_, tl_stride_, Q3_SAMPLE_END, d_temp_.p + b, d_topk_.p + b, d_topp_.p + b,
+                          d_maskeos_.p + b, d_rngkey_.p + (size_t)b * 8, d_draws_.p + b, d_keys_.p + (size_t)b * 16, 16};
+            launch_sample(st_, sa, 1);
+        }
+        Q3_HIP(hipStreamSynchronize(st_));
+        n_prefilling_ = 0;
+        const double t = now_ms();
+        std::lock_guard<std::mutex> lk(mu_);
+        for (Req* r : batch) r->prefill_ms = t - r->t_submit;
+        n_active_ += (int)batch.size();
+    } else {
+        std::lock_guard<std::mutex> lk(mu_);
+        n_active_ += (int)batch.size();
+    }
+}
+
 void Engine::finish_ar(Req* r) { // engine.rs:644-649: final flush of the chunker, then the decoder drains
     r->chunker->push(nullptr, 0, true);
     const int b = r->slot;
     {
         std::lock_guard<std::mutex> lk(mu_);
-        slot_req_[b] = nullptr; n_active_--;
+        slot_req_[b] = nullptr; slot_live_[b] = 0; n_active_--;
         r->slot = -1;
         if (r->want_pcm) { r->state = REQ_DRAINING; n_draining_++; }
         else { r->state = REQ_DONE; r->t_done = now_ms(); cv_.notify_all(); }
@@ -536,8 +649,7 @@ void Engine::finish_ar(Req* r) { // engine.rs:644-649: final flush of the chunke
         dcv_.notify_all();
     }
     h_fin_[b] = 1; h_maxf_[b] = 0; h_nfr_[b] = 0; h_nprompt_[b] = 0; h_temp_[b] = 0.0f; h_mask_[b] = -1;
-    kv_t_->release(b);
-    kv_t_->ensure(b, 1, st_); // idle slots keep stepping inside the graph; they write to their one reserved page
+    kv_t_->release(b); // from the next group on the slot steps on the scratch sequence (upload_slot_state)
     slot_dirty_ = true;
 }
 
@@ -552,7 +664,8 @@ void Engine::run_group() {
     int hi = 0, remaining = 0;
     bool sampled = false;
     for (int b = 0; b < B_; b++)
-        if (Req* r = slot_req_[b]) {
+        if (slot_live_[b]) {
+            Req* r = slot_req_[b];
             hi = b + 1;
             remaining = std::max(remaining, r->r.max_steps - h_nfr_[b]);
             if (r->r.sampler.temperature > 0.0f) sampled = true;
@@ -577,7 +690,8 @@ void Engine::run_group() {
     const int32_t* p_fin = (const int32_t*)d2h_begin(d_finished_.p, (size_t)width * 4);
     std::vector<const int32_t*> p_hist(width, nullptr);
     for (int b = 0; b < width; b++)
-        if (Req* r = slot_req_[b]) {
+        if (slot_live_[b]) {
+            Req* r = slot_req_[b];
             const int rows = std::min(group, r->r.max_steps - r->fed);
             if (rows > 0) p_hist[b] = (const int32_t*)d2h_begin(d_hist_.p + (size_t)b * hist_stride_ + (size_t)r->fed * 16, (size_t)rows * 64);
         }
@@ -592,8 +706,8 @@ void Engine::run_group() {
     }
     std::memcpy(h_nfr_.data(), p_nfr, (size_t)width * 4); std::memcpy(h_fin_.data(), p_fin, (size_t)width * 4);
     for (int b = 0; b < width; b++) {
+        if (!slot_live_[b]) continue;
         Req* r = slot_req_[b];
-        if (!r) continue;
         if (h_nfr_[b] > r->fed) { // hand new frames to the chunker (engine.rs:613-620)
             const int nnew = h_nfr_[b] - r->fed;
             const int32_t* hbuf = p_hist[b];
@@ -617,9 +731,14 @@ bool Engine::step() {
     const double t0 = now_ms();
     harvest(false);
     const double t1 = now_ms();
+    if (async_pf_ && n_prefilling_ > 0) { // has the admission wave finished its prefill?  (wait for it when nothing else can run)
+        if (n_active_ == 0) Q3_HIP(hipEventSynchronize(pf_done_));
+        if (hipEventQuery(pf_done_) == hipSuccess) activate();
+    }
     admit();
     const double t2 = now_ms();
     if (n_active_ > 0) run_group();
+    else if (n_prefilling_ > 0) { Q3_HIP(hipEventSynchronize(pf_done_)); activate(); }
     else if (n_draining_ > 0) harvest(true);
     const double t3 = now_ms();
     if (g_trace) {
@@ -628,7 +747,7 @@ bool Engine::step() {
                 stats.frame_loop_ms, stats.prefill_ms);
     }
     std::lock_guard<std::mutex> lk(mu_);
-    return n_active_ > 0 || n_draining_ > 0 || !pending_.empty();
+    return n_active_ > 0 || n_prefilling_ > 0 || n_draining_ > 0 || !pending_.empty();
 }
 
 ReqStatus Engine::poll(int64_t id) {

@@ -106,6 +106,11 @@ private:
     void record_frame(FrameGraph& fg, bool sampled);  // enqueue one frame step for fg.width slots on st_
     FrameGraph& frame_graph(int width, bool sampled, bool capture);
     void prefill(const std::vector<Req*>& batch, bool sampled);
+    // Asynchronous admission (engines with more than one slot): the prompt of newly admitted requests is prefilled by a second talker
+    // instance (own weights copy, own scratch, own stream) while the frame graph keeps stepping the running sequences; the slots
+    // join the batch ("activate") between two frame groups once the prefill event has completed.
+    void prefill_async(const std::vector<Req*>& batch);
+    void activate();
     void admit();
     void run_group();
     void harvest(bool block);
@@ -124,7 +129,11 @@ private:
     std::vector<hipStream_t> st2_; // codec decoder lanes: overlapped with the next AR frames and with each other
     float* pcm_pinned_ = nullptr; size_t slot_cap_ = 0;
     std::unique_ptr<HostAssets> assets_;
-    std::unique_ptr<Transformer> talker_, predictor_;
+    std::unique_ptr<Transformer> talker_, predictor_, talker_pf_;
+    hipStream_t st_pf_ = nullptr; unsigned char* arena_pf_ = nullptr; size_t arena_pf_cap_ = 0;
+    DevBuf<float> d_prompt_pf_, d_pf_logits_, d_pf_hidden_; DevBuf<int32_t> d_pfa_seq_, d_pfa_slot_, d_pfa_pos_;
+    std::vector<Req*> pf_batch_; hipEvent_t pf_done_ = nullptr, pf_e0_ = nullptr; bool async_pf_ = false; int n_prefilling_ = 0;
+    std::vector<char> slot_live_;      // slot_req_[b] set = reserved; live = stepping inside the frame graph
     std::unique_ptr<KvPool> kv_t_, kv_p_;
     std::unique_ptr<CodecDecoder> codec_;
     // device assets
