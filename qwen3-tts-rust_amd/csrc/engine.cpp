@@ -481,7 +481,8 @@ void Engine::admit() {
         // already cover the whole queue (a synchronous prefill stalls every running sequence; an asynchronous one still shares the GPU)
         int reserved = 0;
         for (int b = 0; b < B_; b++) if (slot_req_[b]) reserved++;
-        const int free_slots = B_ - reserved, quantum = std::max(1, B_ / 8);
+        static const int quantum_div = [] { const char* e = std::getenv("Q3_ADMIT_DIV"); return e ? std::max(1, atoi(e)) : 8; }();
+        const int free_slots = B_ - reserved, quantum = std::max(1, B_ / quantum_div);
         if (free_slots < quantum && n_active_ > 0 && free_slots < (int)pending_.size()) return;
         size_t rows = 0;
         while (!pending_.empty() && reserved < B_) {
