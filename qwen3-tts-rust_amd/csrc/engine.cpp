@@ -488,7 +488,7 @@ void Engine::admit() {
         while (!pending_.empty() && reserved < B_) {
             Req* r = pending_.front();
             if (r->want_pcm && cs_free_.empty()) break; // every codec stream still drains: admit after the next harvest
-            if (async_pf_ && !batch.empty() && rows + (size_t)r->r.n_prompt > 4096) break; // staging arena of one wave
+            if (async_pf_ && n_active_ > 0 && !batch.empty() && rows + (size_t)r->r.n_prompt > 4096) break; // staging arena of one asynchronous wave
             int slot = -1;
             for (int b = 0; b < B_; b++) if (!slot_req_[b]) { slot = b; break; }
             if (slot < 0) break;
@@ -514,8 +514,8 @@ void Engine::admit() {
         }));
         Q3_HIP(hipEventCreate(&r->ev_admit));
     }
-    if (async_pf_) { prefill_async(batch); return; }
-    // ---- synchronous form (single-slot engines: lowest latency, nothing else is running) ----
+    if (async_pf_ && n_active_ > 0) { prefill_async(batch); return; } // sequences are running: do not stall them
+    // ---- in-line form (nothing is running, or a single-slot engine): one batched prefill of the whole wave on the AR stream ----
     arena_used_ = 0; // st_ is idle between scheduler operations
     for (Req* r : batch) kv_t_->release(r->slot), kv_t_->ensure(r->slot, r->r.n_prompt + r->r.max_steps + 1, st_);
     pf_batch_ = batch;
@@ -612,7 +612,7 @@ void Engine::activate() {
         slot_live_[b] = 1;
     }
     upload_slot_state();
-    if (async_pf_) {
+    if (n_prefilling_ > 0) { // the wave was prefilled on the second talker instance
         float ms = 0;
         Q3_HIP(hipEventElapsedTime(&ms, pf_e0_, pf_done_));
         stats.prefill_ms += ms;
