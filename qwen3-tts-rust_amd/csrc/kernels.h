@@ -83,20 +83,9 @@ void launch_project(hipStream_t st, const float* x, int x_stride, const float* W
 void launch_project_table(hipStream_t st, const float* table, int64_t rows, const float* Wt, const float* b, int n_in,
                           int n_out, float* out);
 
-// engine.rs:622-631 : fb = (((0 + E0[c0]) + E1[c1]) ... + E15[c15]) + tts_pad
-void launch_feedback(hipStream_t st, const float* const* tables /*device [16]*/, const int64_t* table_rows /*device[16]*/,
-                     const int32_t* codes, int codes_stride, const float* tts_pad, float* out, int ntok);
-
 void launch_argmax_keys(hipStream_t st, const float* logits, int stride, int n, const int32_t* mask_per_tok, unsigned long long* keys,
                         int key_stride, int ntok);
-void launch_gather_rows(hipStream_t st, const float* table, int64_t rows, const int32_t* idx, int idx_stride, int row_len,
-                        float* dst, int ntok);
 
-struct AdvanceArgs {
-    int B; int32_t *finished, *n_frames; const int32_t* max_frames; const int32_t* cur_codes; int32_t* hist; int hist_stride;
-    int32_t *t_slot, *t_pos;
-};
-void launch_advance(hipStream_t st, const AdvanceArgs& a);
 
 void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
 
@@ -134,8 +123,6 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
 void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
                        const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                        const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok);
-void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
-                         float* out, int out_stride, int ntok);
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk /*[n_out/16][n_in][16]*/, const float* b,
                         int n_in, int n_out, float* out, int out_stride, int ntok);
 void launch_feedback_keys(hipStream_t st, const float* const* tables, const int64_t* table_rows, const q3_u64* keys, int key_stride,

@@ -817,29 +817,6 @@ void launch_project_table(hipStream_t st, const float* table, int64_t rows, cons
                        CT * n_in * sizeof(float), st, table, rows, Wt, b, n_in, n_out, out);
 }
 
-// =====================================================================================================
-// feedback embedding (engine.rs:622-631)
-// =====================================================================================================
-__global__ void __launch_bounds__(256) k_feedback(const float* const* __restrict__ tables, const int64_t* __restrict__ table_rows,
-                                                  const int32_t* __restrict__ codes, int codes_stride,
-                                                  const float* __restrict__ tts_pad, float* __restrict__ out) {
-    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    float acc = 0.0f;
-#pragma unroll
-    for (int q = 0; q < 16; q++) {
-        int c = codes[(size_t)tok * codes_stride + q];
-        if (c < 0) c = 0; // assets_manager.rs:422
-        const float v = ((int64_t)c < table_rows[q]) ? tables[q][(size_t)c * 2048 + i] : 0.0f; // OOB -> zeros (:436)
-        acc = acc + v;
-    }
-    acc = acc + tts_pad[i];
-    out[(size_t)tok * 2048 + i] = acc;
-}
-void launch_feedback(hipStream_t st, const float* const* tables, const int64_t* table_rows, const int32_t* codes,
-                     int codes_stride, const float* tts_pad, float* out, int ntok) {
-    hipLaunchKernelGGL(k_feedback, dim3(8, ntok), dim3(256), 0, st, tables, table_rows, codes, codes_stride, tts_pad, out);
-}
-
 // argmax over stored logits -> argmax key (batched-step path; same first-max semantics as the fused epilogue)
 __global__ void __launch_bounds__(256) k_argmax_keys(const float* __restrict__ logits, int stride, int n, const int32_t* __restrict__ mask_per_tok,
                                                      unsigned long long* __restrict__ keys, int key_stride) {
@@ -861,36 +838,6 @@ void launch_argmax_keys(hipStream_t st, const float* logits, int stride, int n, 
     hipLaunchKernelGGL(k_argmax_keys, dim3(ntok), dim3(256), 0, st, logits, stride, n, mask_per_tok, keys, key_stride);
 }
 
-// row gather: dst[tok][:] = table[max(idx,0)][:]  (pre-projected codec rows -> predictor input)
-__global__ void __launch_bounds__(256) k_gather_rows(const float* __restrict__ table, int64_t rows, const int32_t* __restrict__ idx,
-                                                     int idx_stride, int row_len, float* __restrict__ dst) {
-    const int tok = blockIdx.y, i = blockIdx.x * 256 + threadIdx.x;
-    if (i >= row_len) return;
-    int c = idx[(size_t)tok * idx_stride];
-    if (c < 0) c = 0;
-    dst[(size_t)tok * row_len + i] = ((int64_t)c < rows) ? table[(size_t)c * row_len + i] : 0.0f;
-}
-void launch_gather_rows(hipStream_t st, const float* table, int64_t rows, const int32_t* idx, int idx_stride, int row_len,
-                        float* dst, int ntok) {
-    hipLaunchKernelGGL(k_gather_rows, dim3((row_len + 255) / 256, ntok), dim3(256), 0, st, table, rows, idx, idx_stride, row_len, dst);
-}
-
-// end-of-frame bookkeeping for each sequence (engine.rs:558-562 EOS test, :613-620 code hand-off, :641 cur_pos += 1)
-__global__ void k_advance(AdvanceArgs a) {
-    const int b = blockIdx.x * 64 + threadIdx.x;
-    if (b >= a.B) return;
-    if (a.finished[b] || a.n_frames[b] >= a.max_frames[b]) return; // idle / done: slot stays put (rewrites one slot)
-    const int c0 = a.cur_codes[b * 16];
-    if (c0 == Q3_CODEC_EOS || c0 == Q3_TEXT_EOS) { a.finished[b] = 1; return; }
-    int32_t* dst = a.hist + (size_t)b * a.hist_stride + (size_t)a.n_frames[b] * 16;
-    for (int q = 0; q < 16; q++) dst[q] = a.cur_codes[b * 16 + q];
-    a.n_frames[b] = a.n_frames[b] + 1;
-    a.t_slot[b] = a.t_slot[b] + 1;
-    a.t_pos[b * 4 + 0] += 1; a.t_pos[b * 4 + 1] += 1; a.t_pos[b * 4 + 2] += 1; // engine.rs:306-314: stream 3 stays 0
-}
-void launch_advance(hipStream_t st, const AdvanceArgs& a) {
-    hipLaunchKernelGGL(k_advance, dim3((a.B + 63) / 64), dim3(64), 0, st, a);
-}
 
 // =====================================================================================================
 // float-weight GEMV (bf16 / f16 / f32 rows, row-major as stored in the GGUF): one wave per output row; lane l owns the

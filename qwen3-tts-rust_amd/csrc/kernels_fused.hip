@@ -754,40 +754,8 @@ void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* 
 }
 
 // ===================================================================================================
-// projection with deep prefetch: one thread per output, 32 weight loads in flight per lane, sequential chain
-// (assets_manager.rs:383-399 order preserved exactly)
+// projection (assets_manager.rs:383-399 order preserved exactly)
 // ===================================================================================================
-__global__ void __launch_bounds__(64) k_project_fast(const float* __restrict__ x, int x_stride, const float* __restrict__ Wt,
-                                                     const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
-                                                     int out_stride) {
-    extern __shared__ float xs[];
-    const int tok = blockIdx.y, o = blockIdx.x * 64 + threadIdx.x;
-    for (int i = threadIdx.x; i < n_in; i += 64) xs[i] = x[(size_t)tok * x_stride + i];
-    __syncthreads();
-    const int oo = o < n_out ? o : n_out - 1;
-    float sum = b[oo];
-    const float* wp = Wt + oo;
-    float wbuf[32];
-#pragma unroll
-    for (int j = 0; j < 32; j++) wbuf[j] = wp[(size_t)j * n_out];
-    for (int i0 = 0; i0 < n_in; i0 += 32) {
-        float wn[32];
-        const bool more = i0 + 32 < n_in;
-#pragma unroll
-        for (int j = 0; j < 32; j++) wn[j] = more ? wp[(size_t)(i0 + 32 + j) * n_out] : 0.0f;
-#pragma unroll
-        for (int j = 0; j < 32; j++) { const float t = xs[i0 + j] * wbuf[j]; sum = sum + t; }
-#pragma unroll
-        for (int j = 0; j < 32; j++) wbuf[j] = wn[j];
-    }
-    if (o < n_out) out[(size_t)tok * out_stride + o] = sum;
-}
-void launch_project_fast(hipStream_t st, const float* x, int x_stride, const float* Wt, const float* b, int n_in, int n_out,
-                         float* out, int out_stride, int ntok) {
-    hipLaunchKernelGGL(k_project_fast, dim3((n_out + 63) / 64, ntok), dim3(64), n_in * sizeof(float), st, x, x_stride, Wt, b, n_in,
-                       n_out, out, out_stride);
-}
-
 // Blocked form: Wblk is [n_out/16][n_in][16] so a workgroup's 16 output columns are one contiguous slab that is
 // staged whole in LDS (n_in*64 B) by all 256 threads; 16 lanes then run the reference-ordered chains from LDS.
 __global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x, int x_stride, const float* __restrict__ Wblk,
