@@ -76,6 +76,9 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     kv_t_.reset(new KvPool(talker_->hp().n_layer, talker_->hp().n_kv, B * pages_per_seq + 1, B + 1, pages_per_seq));
     kv_p_.reset(new KvPool(predictor_->hp().n_layer, predictor_->hp().n_kv, B, B, 1));
     for (int b = 0; b < B; b++) kv_p_->ensure(b, 16);
+    pred_identity_pages_ = true; // sequence b owns physical page b: the predictor's attention can skip the page-table lookup
+    for (int b = 0; b < B; b++) if (kv_p_->page(b, 0) != b) pred_identity_pages_ = false;
+    if (const char* e = std::getenv("Q3_UNIFORM_META")) if (e[0] == '0') pred_identity_pages_ = false;
     kv_t_->ensure(B, 1);
     {
         const char* e = std::getenv("Q3_ASYNC_PREFILL");
@@ -225,8 +228,10 @@ void Engine::record_frame(FrameGraph& fg, bool sampled) {
     predictor_->set_same_seq_tokens(false);
     for (int q = 1; q < 15; q++) { // :602-610 decode project(E_q[code_q]) at pos q+1
         TokMeta tm{d_pseq_.p, d_pslot_.p + (size_t)(q + 1) * B_, d_ppos_.p + (size_t)(q + 1) * B_ * 4};
+        KvCache kvq = kvp;
+        if (pred_identity_pages_) { tm.uniform_pos = q + 1; kvq.page_table = nullptr; } // token t = sequence t = page t, position q+1 everywhere
         Transformer::Input in; in.x = d_proj_tab_[q].p; in.x_stride = dP_; in.idx_keys = d_keys_.p + q; in.idx_stride = 16;
-        predictor_->forward(st_, in, B, tm, kvp, nullptr);
+        predictor_->forward(st_, in, B, tm, kvq, nullptr);
         ArgmaxEpi am{d_keys_.p + q + 1, 16, nullptr, 0};
         predictor_->head(st_, 0, B, q * Q3_CODEBOOK_SIZE, Q3_CODEBOOK_SIZE, nullptr, 0, &am);
     }

@@ -151,7 +151,7 @@ private:
     DevBuf<int32_t> d_pf_seq_, d_pf_slot_, d_pf_pos_;
     int hist_stride_ = 0, tl_stride_ = 0;
     std::map<int, std::unique_ptr<FrameGraph>> graphs_; // key = width*2 + sampled
-    bool instrument_ = false;
+    bool instrument_ = false; bool pred_identity_pages_ = false;
     // host mirrors of the slot state (refreshed from the device after every frame group)
     std::vector<int32_t> h_maxf_, h_fin_, h_nfr_, h_mask_, h_nprompt_, h_topk_;
     std::vector<float> h_temp_, h_topp_;

@@ -27,16 +27,23 @@ struct TokMeta {
     const int32_t* seq;    // [ntok] sequence slot (page-table row)
     const int32_t* slot;   // [ntok] cache position this token is written to (= #cached before it)
     const int32_t* pos;    // [ntok][4] M-RoPE position streams (engine.rs:306-314)
+    // Uniform form (the code predictor's passes: token t is sequence t, every token sits at the same position p in all four streams,
+    // engine.rs:316-318): a value >= 0 replaces the three arrays, which removes two dependent global loads from the attention kernels.
+    int uniform_pos = -1;
+    __device__ __forceinline__ int seq_of(int tok) const { return uniform_pos >= 0 ? tok : seq[tok]; }
+    __device__ __forceinline__ int slot_of(int tok) const { return uniform_pos >= 0 ? uniform_pos : slot[tok]; }
+    __device__ __forceinline__ int pos_of(int tok, int stream) const { return uniform_pos >= 0 ? uniform_pos : pos[(size_t)tok * 4 + stream]; }
 };
 
 struct KvCache {           // paged f16 KV cache (pages of 64 positions)
     uint16_t* k;           // [page][layer][kvh][16 dchunks][64 pos][8]
     uint16_t* v;           // [page][layer][kvh][64 pos][128]
-    const int32_t* page_table; // [n_seq][max_pages]
+    const int32_t* page_table; // [n_seq][max_pages]; null = identity (sequence s owns page s, single-page contexts)
     int max_pages;
     int n_layer, n_kv;
     __host__ __device__ size_t page_stride() const { return (size_t)n_layer * n_kv * 8192; } // halfs per page (per K or V)
     __host__ __device__ size_t layer_stride() const { return (size_t)n_kv * 8192; }
+    __device__ __forceinline__ int page_of(int seq, int logical) const { return page_table ? page_table[(size_t)seq * max_pages + logical] : seq; }
 };
 
 // out[(sseg*ntok + tok)*out_stride + r] = super-segment partial of row (row0+r) . x[tok]      (spec S3)

@@ -529,8 +529,8 @@ __global__ void __launch_bounds__(64) k_qk_rope_append(const float* __restrict__
     const int hv = blockIdx.x, tok = blockIdx.y, lane = threadIdx.x;
     const float* vec = qkv + (size_t)tok * qkv_stride + (size_t)hv * 128;
     float x1 = vec[lane], x2 = vec[lane + 64];
-    const int seq = tm.seq[tok], slot = tm.slot[tok];
-    const int page = kv.page_table[(size_t)seq * kv.max_pages + (slot >> 6)];
+    const int seq = tm.seq_of(tok), slot = tm.slot_of(tok);
+    const int page = kv.page_of(seq, slot >> 6);
     const int ps = slot & 63;
     if (hv < n_head + n_kv) {
         const float* w = hv < n_head ? q_norm_w : k_norm_w;
@@ -541,7 +541,7 @@ __global__ void __launch_bounds__(64) k_qk_rope_append(const float* __restrict__
         const float scale = 1.0f / q3_sqrtf(mean + eps);
         const float y1 = (x1 * scale) * w[lane], y2 = (x2 * scale) * w[lane + 64];
         int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-        int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+        int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
         if (pp < 0) pp = 0;
         if (pp > n_ctx - 1) pp = n_ctx - 1;
         float o1, o2;
@@ -584,9 +584,8 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qro
     __shared__ float red_s[4][128];
     __shared__ float wmax_s[4];
     const int h = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seq = tm.seq[tok], n = tm.slot[tok] + 1;
+    const int seq = tm.seq_of(tok), n = tm.slot_of(tok) + 1;
     const int kvh = h / (n_head / n_kv);
-    const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
     const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
     if (tid < 128) q_s[tid] = qrot[((size_t)tok * n_head + h) * 128 + tid];
     __syncthreads();
@@ -600,7 +599,7 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qro
         const bool valid = (jbase + lane) < n;
         float s = -INFINITY;
         if (jbase < n) {
-            const int page = pt[jbase >> 6];
+            const int page = kv.page_of(seq, jbase >> 6);
             const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
             float acc = 0.0f;
 #pragma unroll
@@ -635,7 +634,7 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qro
                 const float pj = p_s[jl];
                 uint4 vv = make_uint4(0, 0, 0, 0);
                 if (jg < n) {
-                    const int page = pt[jg >> 6];
+                    const int page = kv.page_of(seq, jg >> 6);
                     vv = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
                 }
                 S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);

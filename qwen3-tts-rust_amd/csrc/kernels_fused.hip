@@ -348,9 +348,8 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
     __shared__ float red_s[4][128];
     __shared__ float wmax_s[4];
     const int h = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int seq = tm.seq[tok], slot = tm.slot[tok], n = slot + 1;
+    const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
     const int grp = n_head / n_kv, kvh = h / grp;
-    const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
     const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
     const int jj = lane >> 4, dc = lane & 15;
     // ---- latency plan: every global load of the first 256-chunk is issued before the prologue's arithmetic ----
@@ -359,7 +358,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
     {
         const int jbase = wave * 64;
         if (jbase < n) {
-            const int page = pt[jbase >> 6];
+            const int page = kv.page_of(seq, jbase >> 6);
             const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
 #pragma unroll
             for (int d8 = 0; d8 < 16; d8++) kreg[d8] = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
@@ -369,7 +368,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
             const int jg = 16 * u + 4 * wave + jj;
             vreg[u] = make_uint4(0, 0, 0, 0);
             if (jg < n && jg != slot) {
-                const int page = pt[jg >> 6];
+                const int page = kv.page_of(seq, jg >> 6);
                 vreg[u] = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
             }
         }
@@ -378,12 +377,12 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
     if (wave < 3) {
         const float* vec = qkv + (size_t)tok * qkv_stride + (wave == 0 ? (size_t)h * 128 : wave == 1 ? (size_t)(n_head + kvh) * 128 : (size_t)(n_head + n_kv + kvh) * 128);
         const float x1 = vec[lane], x2 = vec[lane + 64];
-        const int page = pt[slot >> 6], ps = slot & 63;
+        const int page = kv.page_of(seq, slot >> 6), ps = slot & 63;
         if (wave < 2) {
             const float* wn = wave == 0 ? q_norm_w : k_norm_w;
             const float w1 = wn[lane], w2 = wn[lane + 64];
             int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-            int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+            int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
             if (pp < 0) pp = 0;
             if (pp > n_ctx - 1) pp = n_ctx - 1;
             const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
@@ -425,7 +424,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         const bool valid = jme < n;
         if (c0 > 0) { // later chunks: load here (the first chunk was prefetched above)
             if (jbase < n) {
-                const int page = pt[jbase >> 6];
+                const int page = kv.page_of(seq, jbase >> 6);
                 const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
 #pragma unroll
                 for (int d8 = 0; d8 < 16; d8++) kreg[d8] = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
@@ -435,7 +434,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
                 const int jg = c0 + 16 * u + 4 * wave + jj;
                 vreg[u] = make_uint4(0, 0, 0, 0);
                 if (jg < n && jg != slot) {
-                    const int page = pt[jg >> 6];
+                    const int page = kv.page_of(seq, jg >> 6);
                     vreg[u] = *reinterpret_cast<const uint4*>(kv.v + (size_t)page * kv.page_stride() + head_off + (jg & 63) * 128 + dc * 8);
                 }
             }
@@ -583,15 +582,14 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
         acc[m] = 0.0f;
         if (m >= ntok) continue;
         const int tok = m;
-        const int seq = tm.seq[tok], slot = tm.slot[tok], n = slot + 1;
-        const int32_t* pt = kv.page_table + (size_t)seq * kv.max_pages;
+        const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
         const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
-        const int page = pt[0]; // n <= 64: a single page
+        const int page = kv.page_of(seq, 0); // n <= 64: a single page
         const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
         const uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
         // ---- this token's q (2 heads), k, v for the group: norm + RoPE; lane owns the pair (l, l+64) ----
         int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-        int pp = tm.pos[(size_t)tok * 4 + q3_mrope_stream(lane, sec)];
+        int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
         if (pp < 0) pp = 0;
         if (pp > n_ctx - 1) pp = n_ctx - 1;
         const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];

@@ -101,6 +101,7 @@ public:
     void ensure(int seq, int n_positions, hipStream_t st);      // same; the table row is uploaded asynchronously on `st`
     void release(int seq);
     int pages_free() const { return (int)free_.size(); }
+    int page(int seq, int logical_page) const { return table_[(size_t)seq * max_pages_ + logical_page]; }
     size_t bytes() const { return (k_.n + v_.n) * 2; }
 private:
     int n_layer_, n_kv_, n_pages_, n_seq_, max_pages_;
