@@ -406,6 +406,21 @@ def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     ge.close(); oe.close()
 
 
+def test_q5_k_m_wide_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
+    """Q5_K_M with 12 concurrent sequences: the mixed-type GEMV's token tiles (grid.z) and the batched layer path for K-quants"""
+    qdir = os.path.join(tiny_model, "gguf_q5_k_m")
+    ge = gpu.Engine(tiny_model, "q5_k_m", max_batch=12, max_steps=16, load_codec=False)
+    oe = oracle.Engine(qdir, None, 4)
+    rng = np.random.default_rng(71)
+    prompts = [ge.assets.build_core(rng.integers(0, 4000, 2 + 3 * i).astype(np.int32), lang_id=2055, spk_emb=vivian) for i in range(12)]
+    res = ge.generate_batch(prompts, max_steps=[4 + i % 3 for i in range(12)], temperature=[0.0 if i % 4 else 0.6 for i in range(12)], top_k=25, top_p=0.9,
+                            seed=[300 + i for i in range(12)], mask_eos=True)
+    for i, (p, r) in enumerate(zip(prompts, res)):
+        oc, _ = oe.generate(p, max_steps=4 + i % 3, temperature=(0.0 if i % 4 else 0.6), top_k=25, top_p=0.9, seed=300 + i, mask_eos=True)
+        assert np.array_equal(oc, r["codes"]), i
+    ge.close(); oe.close()
+
+
 def test_bf16_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     """BASELINE.json configs[4] weight type (bf16): f32 activations, float-weight GEMV (spec S3 float form), bit-exact tokens."""
     qdir = os.path.join(tiny_model, "gguf_bf16")
