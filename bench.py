@@ -85,6 +85,8 @@ def main():
     ap.add_argument("--batch", type=int, default=1, help="sequence slots per GPU (1 = config C2, 64 = config C3)")
     ap.add_argument("--requests", type=int, default=0, help="utterances per GPU (default = --batch); more than --batch queue up and are "
                                                             "admitted by the continuous-batching scheduler as slots retire")
+    ap.add_argument("--clone", action="store_true", help="config C5 prompts: voice-clone layout (62 reference frames + 24 reference-text ids + 32 text "
+                                                          "ids = 133 rows), 4 distinct voices round-robin")
     ap.add_argument("--ragged", action="store_true", help="utterance lengths 50..100 %% of 4*steps frames (slots retire at different times)")
     args = ap.parse_args()
 
@@ -134,7 +136,19 @@ def main():
     log("engine up, prompt rows %d" % prompt.shape[0])
 
     n_req = max(args.requests, args.batch)
-    prompts = [prompt] if n_req == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(n_req)]
+    if args.clone:  # clone prompts, 4 voices (the speaker embeddings are perturbations of the broadcast one; codes are seeded)
+        voices = []
+        for v in range(4):
+            vr = np.random.default_rng(1000 + v)
+            voices.append(((spk_emb * (1.0 - 0.1 * v) + 0.01 * vr.standard_normal(2048)).astype(np.float32), vr.integers(0, 2048, 62 * 16).astype(np.int32),
+                           vr.integers(0, 4000, 24).astype(np.int32)))
+        prompts = []
+        for i in range(n_req):
+            se, rc, rt = voices[i % 4]
+            prompts.append(eng.assets.build_clone(np.random.default_rng(42 + i).integers(0, 4000, 32).astype(np.int32), rc, rt, se))
+        prompt = prompts[0]
+    else:
+        prompts = [prompt] if n_req == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(n_req)]
     last_run = {}
 
     def run(steps, pcm):
@@ -197,8 +211,8 @@ def main():
             "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
             "value": world * audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "i8", "data": "synthetic",
-            "config": {"workload": ("C2 single utterance per GPU" if n_req == 1 else "C3-style %d utterances through %d slots per GPU (continuous batching)" % (n_req, args.batch)) + ", Q3TTS-1.7B-synth Q8_0, greedy, hipGraph 4-frame streaming steps",
+            "dtype": {"bf16": "f32 x bf16 weights", "f16": "f32 x f16 weights"}.get(args.quant, "i8"), "data": "synthetic",
+            "config": {"workload": (("C5-style voice-clone prompts, " if args.clone else "") + ("C2 single utterance per GPU" if n_req == 1 else "C3-style %d utterances through %d slots per GPU (continuous batching)" % (n_req, args.batch))) + ", Q3TTS-1.7B-synth %s, greedy, hipGraph 4-frame streaming steps" % args.quant.upper(),
                        "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": args.batch, "requests_per_gpu": n_req, "ragged": bool(args.ragged),
                        "mean_graph_width": st["slot_frames"] / max(st["graph_frames"], 1),
                        "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
@@ -220,7 +234,8 @@ def main():
         }
         if args.batch > 1:
             # batched steps run the weight-streaming GEMM kernels (k_gemm_q8_mfma / k_gemm_q8_tok); the instrumented family is the line
-            out["roofline"].update({"kernel": "q3::k_gemm_q8_mfma + k_gemv_q8* family (batched step; %d launches)" % fam_n, "achieved": gemv_gbs,
+            fam_name = "q3::k_gemv_float" if args.quant in ("bf16", "f16", "f32") else "q3::k_gemm_q8_mfma + k_gemv_q8*"
+            out["roofline"].update({"kernel": "%s family (batched step; %d launches)" % (fam_name, fam_n), "achieved": gemv_gbs,
                                     "frac": gemv_gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1),
                                     "bytes_per_launch": fam_bytes / max(fam_n, 1), "traffic": None})
         log("instrumented leg done")

@@ -859,49 +859,69 @@ __device__ __forceinline__ void load8(const void* row, int e, float* v) {
         }
     }
 }
-template <int TYPE>
+// MT tokens per workgroup: a weight row chunk is loaded once and applied to MT activation rows (batched steps and prefill read
+// the float weights once per MT tokens instead of once per token); per (row, token) the arithmetic is unchanged.
+template <int TYPE, int MT>
 __global__ void __launch_bounds__(256) k_gemv_float(const void* __restrict__ w, int K, int row0, int nrows, const float* __restrict__ x,
-                                                    int x_stride, float* __restrict__ out, int out_stride) {
+                                                    int x_stride, float* __restrict__ out, int out_stride, int ntok) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave, tok = blockIdx.y;
+    const int r = blockIdx.x * 4 + wave, tok0 = blockIdx.y * MT;
     if (r >= nrows) return;
     const size_t esz = TYPE == Q3_T_F32 ? 4 : 2;
     const char* row = (const char*)w + (size_t)(row0 + r) * K * esz;
-    const float* xv = x + (size_t)tok * x_stride;
     const int nseg = K >> 8;
-    float y = 0.0f, S = 0.0f;
+    float y[MT], S[MT];
+#pragma unroll
+    for (int m = 0; m < MT; m++) { y[m] = 0.0f; S[m] = 0.0f; }
     for (int e0 = 0; e0 < K; e0 += 512) { // one wave instruction covers 512 elements = 2 segments
         const int e = e0 + 8 * lane;
-        float bt = 0.0f;
-        if (e < K) {
-            float wv[8];
-            load8<TYPE>(row, e, wv);
-            const float4 xa = *reinterpret_cast<const float4*>(xv + e), xb = *reinterpret_cast<const float4*>(xv + e + 4);
-            float c = 0.0f;
-            c = q3_fmaf(wv[0], xa.x, c); c = q3_fmaf(wv[1], xa.y, c); c = q3_fmaf(wv[2], xa.z, c); c = q3_fmaf(wv[3], xa.w, c);
-            c = q3_fmaf(wv[4], xb.x, c); c = q3_fmaf(wv[5], xb.y, c); c = q3_fmaf(wv[6], xb.z, c); c = q3_fmaf(wv[7], xb.w, c);
-            const float a = c + __shfl_xor(c, 1); // (c0+c1) | (c2+c3)
-            bt = a + __shfl_xor(a, 2);            // (c0+c1)+(c2+c3)
-        }
+        float wv[8];
+        if (e < K) load8<TYPE>(row, e, wv);
 #pragma unroll
-        for (int sg = 0; sg < 2; sg++) { // the two segments of this load: lanes [32*sg, 32*sg+32)
-            const int s = (e0 >> 8) + sg;
-            if (s < nseg) {
-                float acc = 0.0f;
+        for (int m = 0; m < MT; m++) {
+            int tok = tok0 + m;
+            if (tok > ntok - 1) tok = ntok - 1;
+            const float* xv = x + (size_t)tok * x_stride;
+            float bt = 0.0f;
+            if (e < K) {
+                const float4 xa = *reinterpret_cast<const float4*>(xv + e), xb = *reinterpret_cast<const float4*>(xv + e + 4);
+                float c = 0.0f;
+                c = q3_fmaf(wv[0], xa.x, c); c = q3_fmaf(wv[1], xa.y, c); c = q3_fmaf(wv[2], xa.z, c); c = q3_fmaf(wv[3], xa.w, c);
+                c = q3_fmaf(wv[4], xb.x, c); c = q3_fmaf(wv[5], xb.y, c); c = q3_fmaf(wv[6], xb.z, c); c = q3_fmaf(wv[7], xb.w, c);
+                const float a = c + __shfl_xor(c, 1); // (c0+c1) | (c2+c3)
+                bt = a + __shfl_xor(a, 2);            // (c0+c1)+(c2+c3)
+            }
 #pragma unroll
-                for (int j = 0; j < 8; j++) acc = acc + __shfl(bt, 32 * sg + 4 * j);
-                S = (s % Q3_SSEG_SEGS == 0) ? acc : S + acc;
-                if (s % Q3_SSEG_SEGS == Q3_SSEG_SEGS - 1 || s == nseg - 1) y = (s < Q3_SSEG_SEGS) ? S : y + S;
+            for (int sg = 0; sg < 2; sg++) { // the two segments of this load: lanes [32*sg, 32*sg+32)
+                const int s = (e0 >> 8) + sg;
+                if (s < nseg) {
+                    float acc = 0.0f;
+#pragma unroll
+                    for (int j = 0; j < 8; j++) acc = acc + __shfl(bt, 32 * sg + 4 * j);
+                    S[m] = (s % Q3_SSEG_SEGS == 0) ? acc : S[m] + acc;
+                    if (s % Q3_SSEG_SEGS == Q3_SSEG_SEGS - 1 || s == nseg - 1) y[m] = (s < Q3_SSEG_SEGS) ? S[m] : y[m] + S[m];
+                }
             }
         }
     }
-    if (lane == 0) out[(size_t)tok * out_stride + r] = y;
+    if (lane == 0) {
+#pragma unroll
+        for (int m = 0; m < MT; m++) if (tok0 + m < ntok) out[(size_t)(tok0 + m) * out_stride + r] = y[m];
+    }
+}
+template <int TYPE>
+static void gemv_float_mt(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
+    const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : ntok <= 4 ? 4 : 8;
+    dim3 grid((nrows + 3) / 4, (ntok + mt - 1) / mt);
+    if (mt == 1) hipLaunchKernelGGL((k_gemv_float<TYPE, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemv_float<TYPE, 2>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else if (mt == 4) hipLaunchKernelGGL((k_gemv_float<TYPE, 4>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else hipLaunchKernelGGL((k_gemv_float<TYPE, 8>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
 }
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
-    dim3 grid((nrows + 3) / 4, ntok);
-    if (w.type == Q3_T_F32) hipLaunchKernelGGL((k_gemv_float<Q3_T_F32>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
-    else if (w.type == Q3_T_F16) hipLaunchKernelGGL((k_gemv_float<Q3_T_F16>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
-    else hipLaunchKernelGGL((k_gemv_float<Q3_T_BF16>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride);
+    if (w.type == Q3_T_F32) gemv_float_mt<Q3_T_F32>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else if (w.type == Q3_T_F16) gemv_float_mt<Q3_T_F16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else gemv_float_mt<Q3_T_BF16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
 }
 __global__ void k_swiglu_f32(const float* __restrict__ gu, int ff, float* __restrict__ out) {
     const int tok = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x;
