@@ -859,64 +859,83 @@ __device__ __forceinline__ void load8(const void* row, int e, float* v) {
         }
     }
 }
-// MT tokens per workgroup: a weight row chunk is loaded once and applied to MT activation rows (batched steps and prefill read
-// the float weights once per MT tokens instead of once per token); per (row, token) the arithmetic is unchanged.
-template <int TYPE, int MT>
+__device__ __forceinline__ float quad_xor1(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0xB1, 0xF, 0xF, false)); } // quad_perm [1,0,3,2]
+__device__ __forceinline__ float quad_xor2(float v) { return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), 0x4E, 0xF, 0xF, false)); } // quad_perm [2,3,0,1]
+template <typename T> __device__ __forceinline__ float lane_bcast(float v, T lane_const) { return __int_as_float(__builtin_amdgcn_readlane(__float_as_int(v), lane_const)); }
+// MT tokens x RW rows per wave: a weight row chunk is loaded once and applied to MT activation rows, and an activation chunk is
+// loaded once and applied to RW weight rows (batched steps and prefill: far fewer loads per fma); per (row, token) the arithmetic
+// is unchanged.
+template <int TYPE, int MT, int RW>
 __global__ void __launch_bounds__(256) k_gemv_float(const void* __restrict__ w, int K, int row0, int nrows, const float* __restrict__ x,
                                                     int x_stride, float* __restrict__ out, int out_stride, int ntok) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = blockIdx.x * 4 + wave, tok0 = blockIdx.y * MT;
-    if (r >= nrows) return;
+    const int r0 = (blockIdx.x * 4 + wave) * RW, tok0 = blockIdx.y * MT;
+    if (r0 >= nrows) return;
     const size_t esz = TYPE == Q3_T_F32 ? 4 : 2;
-    const char* row = (const char*)w + (size_t)(row0 + r) * K * esz;
-    const int nseg = K >> 8;
-    float y[MT], S[MT];
+    const char* rows[RW];
 #pragma unroll
-    for (int m = 0; m < MT; m++) { y[m] = 0.0f; S[m] = 0.0f; }
+    for (int q = 0; q < RW; q++) { const int rr = r0 + q < nrows ? r0 + q : nrows - 1; rows[q] = (const char*)w + (size_t)(row0 + rr) * K * esz; }
+    const int nseg = K >> 8;
+    float y[MT][RW], S[MT][RW];
+#pragma unroll
+    for (int m = 0; m < MT; m++)
+#pragma unroll
+        for (int q = 0; q < RW; q++) { y[m][q] = 0.0f; S[m][q] = 0.0f; }
     for (int e0 = 0; e0 < K; e0 += 512) { // one wave instruction covers 512 elements = 2 segments
         const int e = e0 + 8 * lane;
-        float wv[8];
-        if (e < K) load8<TYPE>(row, e, wv);
+        float wv[RW][8];
+        if (e < K) {
+#pragma unroll
+            for (int q = 0; q < RW; q++) load8<TYPE>(rows[q], e, wv[q]);
+        }
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             int tok = tok0 + m;
             if (tok > ntok - 1) tok = ntok - 1;
             const float* xv = x + (size_t)tok * x_stride;
-            float bt = 0.0f;
-            if (e < K) {
-                const float4 xa = *reinterpret_cast<const float4*>(xv + e), xb = *reinterpret_cast<const float4*>(xv + e + 4);
-                float c = 0.0f;
-                c = q3_fmaf(wv[0], xa.x, c); c = q3_fmaf(wv[1], xa.y, c); c = q3_fmaf(wv[2], xa.z, c); c = q3_fmaf(wv[3], xa.w, c);
-                c = q3_fmaf(wv[4], xb.x, c); c = q3_fmaf(wv[5], xb.y, c); c = q3_fmaf(wv[6], xb.z, c); c = q3_fmaf(wv[7], xb.w, c);
-                const float a = c + __shfl_xor(c, 1); // (c0+c1) | (c2+c3)
-                bt = a + __shfl_xor(a, 2);            // (c0+c1)+(c2+c3)
-            }
+            float4 xa = make_float4(0.f, 0.f, 0.f, 0.f), xb = xa;
+            if (e < K) { xa = *reinterpret_cast<const float4*>(xv + e); xb = *reinterpret_cast<const float4*>(xv + e + 4); }
 #pragma unroll
-            for (int sg = 0; sg < 2; sg++) { // the two segments of this load: lanes [32*sg, 32*sg+32)
-                const int s = (e0 >> 8) + sg;
-                if (s < nseg) {
-                    float acc = 0.0f;
+            for (int q = 0; q < RW; q++) {
+                float bt = 0.0f;
+                if (e < K) {
+                    float c = 0.0f;
+                    c = q3_fmaf(wv[q][0], xa.x, c); c = q3_fmaf(wv[q][1], xa.y, c); c = q3_fmaf(wv[q][2], xa.z, c); c = q3_fmaf(wv[q][3], xa.w, c);
+                    c = q3_fmaf(wv[q][4], xb.x, c); c = q3_fmaf(wv[q][5], xb.y, c); c = q3_fmaf(wv[q][6], xb.z, c); c = q3_fmaf(wv[q][7], xb.w, c);
+                    const float a = c + quad_xor1(c); // (c0+c1) | (c2+c3)     (DPP quad permutes: no LDS traffic)
+                    bt = a + quad_xor2(a);            // (c0+c1)+(c2+c3)
+                }
 #pragma unroll
-                    for (int j = 0; j < 8; j++) acc = acc + __shfl(bt, 32 * sg + 4 * j);
-                    S[m] = (s % Q3_SSEG_SEGS == 0) ? acc : S[m] + acc;
-                    if (s % Q3_SSEG_SEGS == Q3_SSEG_SEGS - 1 || s == nseg - 1) y[m] = (s < Q3_SSEG_SEGS) ? S[m] : y[m] + S[m];
+                for (int sg = 0; sg < 2; sg++) { // the two segments of this load: lanes [32*sg, 32*sg+32)
+                    const int s = (e0 >> 8) + sg;
+                    if (s < nseg) {
+                        float acc = 0.0f;
+#pragma unroll
+                        for (int j = 0; j < 8; j++) acc = acc + lane_bcast(bt, 32 * sg + 4 * j); // v_readlane: block sums in order
+                        S[m][q] = (s % Q3_SSEG_SEGS == 0) ? acc : S[m][q] + acc;
+                        if (s % Q3_SSEG_SEGS == Q3_SSEG_SEGS - 1 || s == nseg - 1) y[m][q] = (s < Q3_SSEG_SEGS) ? S[m][q] : y[m][q] + S[m][q];
+                    }
                 }
             }
         }
     }
     if (lane == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; m++) if (tok0 + m < ntok) out[(size_t)(tok0 + m) * out_stride + r] = y[m];
+        for (int m = 0; m < MT; m++)
+#pragma unroll
+            for (int q = 0; q < RW; q++) if (tok0 + m < ntok && r0 + q < nrows) out[(size_t)(tok0 + m) * out_stride + r0 + q] = y[m][q];
     }
 }
 template <int TYPE>
 static void gemv_float_mt(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
     const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : ntok <= 4 ? 4 : 8;
+    // rows per wave (RW) > 1 shares activation loads between rows; measured at 32 sequences, bf16: RW 1 -> 68.8, 2 -> 68.3, 4 -> 60.2 audio-s/s,
+    // so every token count uses one row per wave (the in-order block sums, not the loads, bound this kernel)
     dim3 grid((nrows + 3) / 4, (ntok + mt - 1) / mt);
-    if (mt == 1) hipLaunchKernelGGL((k_gemv_float<TYPE, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
-    else if (mt == 2) hipLaunchKernelGGL((k_gemv_float<TYPE, 2>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
-    else if (mt == 4) hipLaunchKernelGGL((k_gemv_float<TYPE, 4>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
-    else hipLaunchKernelGGL((k_gemv_float<TYPE, 8>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    if (mt == 1) hipLaunchKernelGGL((k_gemv_float<TYPE, 1, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else if (mt == 2) hipLaunchKernelGGL((k_gemv_float<TYPE, 2, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else if (mt == 4) hipLaunchKernelGGL((k_gemv_float<TYPE, 4, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
+    else hipLaunchKernelGGL((k_gemv_float<TYPE, 8, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
 }
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
     if (w.type == Q3_T_F32) gemv_float_mt<Q3_T_F32>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
