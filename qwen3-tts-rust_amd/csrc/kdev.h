@@ -8,14 +8,30 @@ namespace q3 {
 
 __device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 __device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// Exact xor-lane exchanges without LDS traffic (HIP's __shfl_xor lowers to ds_bpermute_b32 + address arithmetic, ~100 cycles of latency
+// per step of a dependent butterfly): DPP quad permutes for 1/2, DPP row shifts + select for 4/8, v_permlane16_swap / v_permlane32_swap
+// (gfx950) for 16/32.  Same pairing as __shfl_xor for every lane (scripts/check_xor_shuffles.hip), so the spec's butterflies keep their bits.
+typedef unsigned q3_u2v __attribute__((ext_vector_type(2)));
+template <int CTRL> __device__ __forceinline__ int dpp_mov_i(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, true); }
+template <int S> __device__ __forceinline__ int xor_lane(int v) {
+    static_assert(S == 1 || S == 2 || S == 4 || S == 8 || S == 16 || S == 32, "xor_lane: power of two below 64");
+    const int lane = threadIdx.x & 63;
+    if (S == 1) return dpp_mov_i<0xB1>(v);                  // quad_perm [1,0,3,2]
+    if (S == 2) return dpp_mov_i<0x4E>(v);                  // quad_perm [2,3,0,1]
+    if (S == 4) { const int a = dpp_mov_i<0x104>(v), b = dpp_mov_i<0x114>(v); return (lane & 4) ? b : a; }   // row_shl:4 / row_shr:4
+    if (S == 8) { const int a = dpp_mov_i<0x108>(v), b = dpp_mov_i<0x118>(v); return (lane & 8) ? b : a; }   // row_shl:8 / row_shr:8
+    if (S == 16) { const q3_u2v r = __builtin_amdgcn_permlane16_swap((unsigned)v, (unsigned)v, false, false); return (int)((lane & 16) ? r[0] : r[1]); }
+    const q3_u2v r = __builtin_amdgcn_permlane32_swap((unsigned)v, (unsigned)v, false, false);
+    return (int)((lane & 32) ? r[0] : r[1]);
+}
+template <int S> __device__ __forceinline__ float xor_lane(float v) { return __int_as_float(xor_lane<S>(__float_as_int(v))); }
 __device__ __forceinline__ float wave_sum_bfly(float v) { // spec butterfly: xor 32,16,8,4,2,1
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = v + __shfl_xor(v, s);
+    v = v + xor_lane<32>(v); v = v + xor_lane<16>(v); v = v + xor_lane<8>(v); v = v + xor_lane<4>(v); v = v + xor_lane<2>(v); v = v + xor_lane<1>(v);
     return v;
 }
 __device__ __forceinline__ float wave_max_bfly(float v) {
-#pragma unroll
-    for (int s = 32; s >= 1; s >>= 1) v = fmaxf(v, __shfl_xor(v, s));
+    v = fmaxf(v, xor_lane<32>(v)); v = fmaxf(v, xor_lane<16>(v)); v = fmaxf(v, xor_lane<8>(v)); v = fmaxf(v, xor_lane<4>(v));
+    v = fmaxf(v, xor_lane<2>(v)); v = fmaxf(v, xor_lane<1>(v));
     return v;
 }
 __device__ __forceinline__ int dot16(const uint4& a, const uint4& b) {

@@ -53,7 +53,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
             for (int i = 0; i < NLD; i++) {
                 const uint4 xv = *reinterpret_cast<const uint4*>(xp + (i * BPL + bil) * 32 + half * 16);
                 int isum = dot16(wv[i], xv);
-                isum += __shfl_xor(isum, R); // the other half of the same 32-block: exact integer add
+                isum += xor_lane<R>(isum); // the other half of the same 32-block: exact integer add
 #pragma unroll
                 for (int j = 0; j < BPL; j++) {
                     const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
@@ -143,12 +143,12 @@ __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, c
                 if (wt == Q3_T_Q5_K) {
                     const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
                     xsum = dot16(ones, xv);
-                    xsum += __shfl_xor(xsum, R);
+                    xsum += xor_lane<R>(xsum);
                 } else if (wt == Q3_T_Q6_K) {
                     const int bsel = i * BPL + bil; // block index inside the segment of THIS lane's data
                     isum *= (int)(int8_t)mbyte(2 * bsel + half);
                 }
-                isum += __shfl_xor(isum, R);
+                isum += xor_lane<R>(isum);
 #pragma unroll
                 for (int j = 0; j < BPL; j++) {
                     const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
@@ -444,8 +444,8 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                 else {
                     const float y = q3_swiglu(gate_s[lt][t], S);
                     float amax = q3_fabsf(y);
-#pragma unroll
-                    for (int s2 = 16; s2 >= 1; s2 >>= 1) amax = fmaxf(amax, __shfl_xor(amax, s2));
+                    amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+                    amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
                     const float dd = amax / 127.0f;
                     const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
                     if (tok < ntok) {
@@ -502,7 +502,7 @@ __global__ void __launch_bounds__(64) k_rmsnorm_quant(NormArgs a) {
             y.z = (x[c].z * scale) * g.z; y.w = (x[c].w * scale) * g.w;
             if (a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * a.d + 256 * c + 4 * lane) = y;
             float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
-            amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+            amax = fmaxf(amax, xor_lane<1>(amax)); amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
             const float dd = amax / 127.0f;
             const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
             const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
@@ -645,8 +645,8 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qro
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float a = S[i] + __shfl_xor(S[i], 16);   // (S0+S1) | (S2+S3)
-            const float T = a + __shfl_xor(a, 32);          // (S0+S1)+(S2+S3)
+            const float a = S[i] + xor_lane<16>(S[i]);   // (S0+S1) | (S2+S3)
+            const float T = a + xor_lane<32>(a);          // (S0+S1)+(S2+S3)
             if (jj == 0) red_s[wave][dc * 8 + i] = T;
         }
         __syncthreads();
@@ -678,8 +678,8 @@ __global__ void __launch_bounds__(256) k_attention(const float* __restrict__ qro
         float amax = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) { y[i] = O[i] / L; amax = fmaxf(amax, q3_fabsf(y[i])); }
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, xor_lane<1>(amax));
+        amax = fmaxf(amax, xor_lane<2>(amax));
         const float dd = amax / 127.0f;
         const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
         if (jj == 0) {
@@ -717,7 +717,7 @@ __global__ void __launch_bounds__(256) k_swiglu_quant(const float* __restrict__ 
     float4 y;
     y.x = q3_swiglu(g.x, u.x); y.y = q3_swiglu(g.y, u.y); y.z = q3_swiglu(g.z, u.z); y.w = q3_swiglu(g.w, u.w);
     float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    amax = fmaxf(amax, xor_lane<1>(amax)); amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
     const float dd = amax / 127.0f;
     const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
     const uint32_t pk = (uint32_t)((int)q3_rintf(y.x * id) & 0xFF) | ((uint32_t)((int)q3_rintf(y.y * id) & 0xFF) << 8) |

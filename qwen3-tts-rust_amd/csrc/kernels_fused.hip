@@ -56,7 +56,7 @@ __device__ __forceinline__ void norm_quant_token(const NormPro& a, int d, int to
             y.z = (x[c].z * scale) * g.z; y.w = (x[c].w * scale) * g.w;
             if (write_global && a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * d + 256 * c + 4 * lane) = y;
             float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
-            amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+            amax = fmaxf(amax, xor_lane<1>(amax)); amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
             const float dd = amax / 127.0f;
             const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
             const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
@@ -119,7 +119,7 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
     y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
     if (tok_valid && write_global && a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * d + 256 * c + 4 * lane) = y;
     float amax = fmaxf(fmaxf(q3_fabsf(y.x), q3_fabsf(y.y)), fmaxf(q3_fabsf(y.z), q3_fabsf(y.w)));
-    amax = fmaxf(amax, __shfl_xor(amax, 1)); amax = fmaxf(amax, __shfl_xor(amax, 2)); amax = fmaxf(amax, __shfl_xor(amax, 4));
+    amax = fmaxf(amax, xor_lane<1>(amax)); amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
     const float dd = amax / 127.0f;
     const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
     const int q0 = (int)q3_rintf(y.x * id), q1 = (int)q3_rintf(y.y * id), q2 = (int)q3_rintf(y.z * id), q3v = (int)q3_rintf(y.w * id);
@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
         for (int i = 0; i < NLD; i++) {
             const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + (i * BPL + bil) * 32 + half * 16]);
             int isum = dot16(wv[i], xv);
-            isum += __shfl_xor(isum, R);
+            isum += xor_lane<R>(isum);
 #pragma unroll
             for (int j = 0; j < BPL; j++) {
                 const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
@@ -291,7 +291,7 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
         for (int i = 0; i < 8; i++) {
             const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
             int ig = dot16(wg[i], xv), iu = dot16(wu[i], xv);
-            ig += __shfl_xor(ig, 32); iu += __shfl_xor(iu, 32);
+            ig += xor_lane<32>(ig); iu += xor_lane<32>(iu);
             const float dx = h2f(half_of(dxv, i));
             ag = q3_fmaf((float)ig, h2f(half_of(dg, i)) * dx, ag);
             au = q3_fmaf((float)iu, h2f(half_of(du, i)) * dx, au);
@@ -305,8 +305,8 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
         for (int s = 1; s < nseg; s++) { G = G + red[s][0][t]; U = U + red[s][1][t]; }
         const float y = q3_swiglu(G, U);
         float amax = q3_fabsf(y);
-#pragma unroll
-        for (int sft = 16; sft >= 1; sft >>= 1) amax = fmaxf(amax, __shfl_xor(amax, sft));
+        amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+        amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
         const float dd = amax / 127.0f;
         const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
         if (tok < ntok) {
@@ -483,8 +483,8 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         }
 #pragma unroll
         for (int i = 0; i < 8; i++) {
-            const float a2 = S[i] + __shfl_xor(S[i], 16);
-            const float T = a2 + __shfl_xor(a2, 32);
+            const float a2 = S[i] + xor_lane<16>(S[i]);
+            const float T = a2 + xor_lane<32>(a2);
             if (jj == 0) red_s[wave][dc * 8 + i] = T;
         }
         __syncthreads();
@@ -516,8 +516,8 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         float amax = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) { y[i] = O[i] / L; amax = fmaxf(amax, q3_fabsf(y[i])); }
-        amax = fmaxf(amax, __shfl_xor(amax, 1));
-        amax = fmaxf(amax, __shfl_xor(amax, 2));
+        amax = fmaxf(amax, xor_lane<1>(amax));
+        amax = fmaxf(amax, xor_lane<2>(amax));
         const float dd = amax / 127.0f;
         const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
         if (jj == 0) {
@@ -675,8 +675,8 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
                 }
 #pragma unroll
                 for (int i = 0; i < 8; i++) {
-                    const float a2 = S[i] + __shfl_xor(S[i], 16);
-                    const float T = a2 + __shfl_xor(a2, 32);
+                    const float a2 = S[i] + xor_lane<16>(S[i]);
+                    const float T = a2 + xor_lane<32>(a2);
                     if (ww == 0) s01[i] = T; else if (ww == 1) s01[i] = s01[i] + T; else if (ww == 2) s23[i] = T; else s23[i] = s23[i] + T;
                 }
             }
@@ -690,8 +690,8 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
             float amax = 0.0f;
 #pragma unroll
             for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
-            amax = fmaxf(amax, __shfl_xor(amax, 1));
-            amax = fmaxf(amax, __shfl_xor(amax, 2));
+            amax = fmaxf(amax, xor_lane<1>(amax));
+            amax = fmaxf(amax, xor_lane<2>(amax));
             const float dd = amax / 127.0f;
             const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
             if (jj == 0) {
@@ -713,7 +713,7 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
         for (int i = 0; i < NLD; i++) {
             const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[wave][(i * BPL + bil) * 32 + half * 16]);
             int isum = dot16(wv[i], xv);
-            isum += __shfl_xor(isum, R);
+            isum += xor_lane<R>(isum);
 #pragma unroll
             for (int j = 0; j < BPL; j++) {
                 const int isj = __shfl(isum, r + 2 * j * R);
