@@ -3,7 +3,9 @@
 set -e
 cd "$(dirname "$0")"
 ARCH=${Q3_ARCH:-gfx950}
-FLAGS="-O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
+# -amdgpu-kernarg-preload-count: the first 16 kernel-argument dwords arrive in SGPRs with the dispatch instead of through an s_load at kernel
+# start (measured 2.918 -> 2.893 ms/frame at B=1); Q3_EXTRA_FLAGS is for experiments
+FLAGS="${Q3_EXTRA_FLAGS:-} -mllvm -amdgpu-kernarg-preload-count=16 -O3 -std=c++17 -fPIC --offload-arch=$ARCH -ffp-contract=off -fno-fast-math -fhip-fp32-correctly-rounded-divide-sqrt -Wall -Wno-unused-function -Wno-unused-result"
 mkdir -p build
 OBJS=""
 PIDS=""
