@@ -11,6 +11,7 @@
 // Arithmetic is include/q3tts_spec.h's, bit-identical to the unfused kernels and to oracle/.
 #include "kernels.h"
 #include "kdev.h"
+#include <cstdlib>
 #include "q3_common.h"
 
 namespace q3 {
@@ -799,7 +800,8 @@ __global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x,
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
                         float* out, int out_stride, int ntok) {
     static bool attr_set = false, attr_mt = false;
-    if (ntok > 2) {
+    static const int mt_min = [] { const char* e = std::getenv("Q3_PROJECT_MT_MIN"); return e ? atoi(e) : 3; }(); // experiment knob
+    if (ntok >= mt_min) {
         if (!attr_mt) { (void)hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_mt = true; }
         hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), (size_t)n_in * 16 * sizeof(float), st, x, x_stride, Wblk, b,
                            n_in, n_out, out, out_stride, ntok);
