@@ -11,8 +11,11 @@
  * in /root/reference or this image.  Source-pinned parts (loop protocol, sampler, projection order,
  * gathers, feedback sum, prompt layout, chunker, mel, file formats) are restated line-for-line in
  * meaning and pinned by known-answer tests derived from the reference source; the transformer block
- * math is pinned against the locally installed transformers Qwen3 modules (tests/golden/, float
- * tolerance); the quantised-matmul rounding and the codec-decoder graph are "parity unpinned".
+ * math is pinned against the locally installed transformers Qwen3 modules (float tolerance), the mel
+ * front end against transformers.audio_utils, the codec building blocks against the transformers
+ * Code2Wav modules, the sampler's ChaCha12 core against a published known-answer vector; the
+ * quantised-matmul rounding (llama.cpp), the exported codec-decoder graph (ONNX), the RNG seed
+ * expansion and the tokenizer remain "parity unpinned".
  */
 #ifndef Q3O_H
 #define Q3O_H
