@@ -766,14 +766,22 @@ __global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x
     const int ob = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x;
     const float4* src = reinterpret_cast<const float4*>(Wblk + (size_t)ob * n_in * 16);
     float4* dst = reinterpret_cast<float4*>(ws);
-    for (int i = tid; i < n_in * 4; i += 256) dst[i] = src[i];
     for (int i = tid; i < n_in; i += 256) xs[i] = x[(size_t)tok * x_stride + i];
+    __syncthreads();
+    // the products x[i]*W[o][i] are independent roundings: all 256 threads form them while staging (t = x*w exactly as the reference's
+    // `x[i] * w[i]`), so the 16 serial chains below only add: sum = (((b + t0) + t1) + ...) in ascending i
+    for (int i = tid; i < n_in * 4; i += 256) {
+        float4 w = src[i];
+        const float xv = xs[i >> 2];
+        w.x = xv * w.x; w.y = xv * w.y; w.z = xv * w.z; w.w = xv * w.w;
+        dst[i] = w;
+    }
     __syncthreads();
     if (tid < 16) {
         const int o = ob * 16 + tid;
         float sum = b[o];
 #pragma unroll 16
-        for (int i = 0; i < n_in; i++) { const float t = xs[i] * ws[i * 16 + tid]; sum = sum + t; }
+        for (int i = 0; i < n_in; i++) sum = sum + ws[i * 16 + tid];
         out[(size_t)tok * out_stride + o] = sum;
     }
 }
