@@ -183,6 +183,10 @@ int q3tts_tf_eval(q3tts_tf* t, const float* x, const int32_t* pos4, int32_t ntok
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,
                      const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);
+/* float-weight matmul (spec S3 float form; ggml types 0 = f32, 1 = f16, 30 = bf16): ntok >= 12 runs the matrix-core kernel,
+ * fewer tokens the one-wave-per-row GEMV; row0 selects a row range like the head of the code predictor does */
+int q3tts_op_matmul_float(const void* w /* [n][k] */, int32_t type, int32_t n, int32_t k, int32_t row0, int32_t nrows,
+                          const float* x /* [ntok][k] */, int32_t ntok, float* y /* [ntok][nrows] */);
 int q3tts_op_rmsnorm_quant(const float* x, const float* g, int32_t d, int32_t ntok, float eps, int8_t* xq, uint16_t* xd,
                            float* xn);
 int q3tts_op_swiglu_quant(const float* gu, int32_t ff, int32_t ntok, int8_t* aq, uint16_t* ad);

@@ -36,6 +36,25 @@ int q3tts_op_gemv_q8(const void* w, int32_t n, int32_t k, const int8_t* xq, cons
     Q3_API_END(Q3TTS_ERR)
 }
 
+int q3tts_op_matmul_float(const void* w, int32_t type, int32_t n, int32_t k, int32_t row0, int32_t nrows, const float* x, int32_t ntok, float* y) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(type == Q3_T_F32 || type == Q3_T_F16 || type == Q3_T_BF16, "float type expected");
+    Q3_CHECK(n > 0 && k > 0 && k % 256 == 0 && ntok > 0 && row0 >= 0 && nrows > 0 && row0 + nrows <= n, "bad matmul shape");
+    const size_t esz = type == Q3_T_F32 ? 4 : 2;
+    DevBuf<uint8_t> dw((size_t)n * k * esz); dw.upload((const uint8_t*)w, dw.n);
+    DevBuf<uint8_t> dwt((size_t)((n + 63) / 64) * 64 * k * esz);
+    launch_tile_float(0, dw.p, dwt.p, type, n, k);
+    FMat m; m.w = dw.p; m.wt = dwt.p; m.type = type; m.N = n; m.K = k;
+    DevBuf<float> dx((size_t)ntok * k); dx.upload(x, dx.n);
+    DevBuf<float> dy((size_t)ntok * nrows);
+    launch_gemv_float(0, m, row0, nrows, dx.p, k, dy.p, nrows, ntok);
+    Q3_HIP(hipDeviceSynchronize());
+    dy.download(y, dy.n);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
 int q3tts_op_rmsnorm_quant(const float* x, const float* g, int32_t d, int32_t ntok, float eps, int8_t* xq, uint16_t* xd, float* xn) {
     Q3_API_BEGIN
     require_gpu();

@@ -36,8 +36,15 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     // 3.07 ms/frame -- the single-wave attention chain costs more than the launch it removes, so it stays off by default.
     if (const char* e = std::getenv("Q3_FOLD_ATTN")) predictor_->set_short_context(e[0] == '1');
     if (const char* e = std::getenv("Q3_PRED_FUSED_MAX")) predictor_->set_fused_max_tokens(atoi(e)); // experiment knob
-    // Tried and rejected for the predictor's <= 17 cached positions: a single-wave attention kernel (no workgroup barriers, two q heads
-    // per wave).  Measured on MI355X: 3.24 vs 3.06 ms/frame -- the serial PV of both heads costs more than the barriers it removes.
+    // The predictor never holds more than 17 positions per sequence: wide steps use the single-wave attention kernel (one wave per
+    // token and kv head, no workgroup barrier).  At one sequence it loses to k_attention_fused (3.24 vs 3.06 ms/frame: the serial PV
+    // of both heads costs more than the barriers it removes), hence the token threshold.
+    {
+        int min_tok = 8;
+        if (const char* e = std::getenv("Q3_SHORT_ATTN_MIN")) min_tok = atoi(e); // 0 = never
+        // (the engine drives the predictor through positions 0..16 only -- 2 prompt rows + 15 code passes -- i.e. one KV page)
+        predictor_->set_short_attention(min_tok);
+    }
     Q3_CHECK(talker_->hp().n_embd == Q3_EMBD, "talker n_embd must be 2048 (reference hard-codes 2048-wide rows)");
     dP_ = predictor_->hp().n_embd;
     Q3_CHECK(assets_->proj_out == dP_ && assets_->proj_in == Q3_EMBD, "proj shape does not match predictor n_embd");

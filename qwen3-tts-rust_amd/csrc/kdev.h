@@ -7,7 +7,10 @@
 namespace q3 {
 
 __device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
-__device__ __forceinline__ uint16_t f2h(float f) { return __builtin_bit_cast(uint16_t, (_Float16)f); }
+// f32 -> f16, round-to-nearest-even of the *f32 value*.  The empty asm makes the operand opaque: without it the backend folds
+// `f2h(fma(a, b, c))` into v_fma_mixlo_f16, which rounds the exact a*b+c once to f16 and differs from the spec's
+// (and the oracle's) two-step rounding on f16 ties -- seen as a one-ulp K difference in ~1/8000 elements.
+__device__ __forceinline__ uint16_t f2h(float f) { asm volatile("" : "+v"(f)); return __builtin_bit_cast(uint16_t, (_Float16)f); }
 // Exact xor-lane exchanges without LDS traffic (HIP's __shfl_xor lowers to ds_bpermute_b32 + address arithmetic, ~100 cycles of latency
 // per step of a dependent butterfly): DPP quad permutes for 1/2, DPP row shifts + select for 4/8, v_permlane16_swap / v_permlane32_swap
 // (gfx950) for 16/32.  Same pairing as __shfl_xor for every lane (scripts/check_xor_shuffles.hip), so the spec's butterflies keep their bits.

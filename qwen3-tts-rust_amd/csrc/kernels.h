@@ -98,8 +98,10 @@ void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
 
 // ---- 16/32-bit float weights (bf16 / f16 / f32 files): f32 activations, no activation quantisation (spec S3 float form:
 // 8-element fma sub-chains, block = (c0+c1)+(c2+c3), blocks added in order inside a segment, segments / super-segments in order)
-struct FMat { const void* w = nullptr; int type = 0; int N = 0, K = 0; size_t bytes() const { return (size_t)N * K * (type == 0 ? 4 : 2); } };
+// w: row-major [N][K]; wt: the same elements tiled [ceil(N/64)][K/8][64][8] for k_gemm_float_mfma (rows past N are zero)
+struct FMat { const void* w = nullptr; const void* wt = nullptr; int type = 0; int N = 0, K = 0; size_t bytes() const { return (size_t)N * K * (type == 0 ? 4 : 2); } };
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok);
+void launch_tile_float(hipStream_t st, const void* w, void* wt, int type, int N, int K);
 void launch_swiglu_f32(hipStream_t st, const float* gu, int ff, float* out, int ntok);
 
 // ------------------------------- fused decode-step kernels (kernels_fused.hip) -------------------------------
@@ -127,6 +129,9 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                             const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad,
                             int ntok);
+void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
+                            const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
+                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok);
 void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
                        const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                        const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok);

@@ -9,6 +9,7 @@
 // before first use, wave-shuffle reductions, and >=256 workgroups per launch.  No MFMA here on purpose.
 #include "kernels.h"
 #include <cstdlib>
+#include "q3_common.h"
 #include "../../include/q3tts_spec.h"
 #include "kdev.h"
 
@@ -937,7 +938,248 @@ static void gemv_float_mt(hipStream_t st, const FMat& w, int row0, int nrows, co
     else if (mt == 4) hipLaunchKernelGGL((k_gemv_float<TYPE, 4, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
     else hipLaunchKernelGGL((k_gemv_float<TYPE, 8, 1>), grid, dim3(256), 0, st, w.w, w.K, row0, nrows, x, x_stride, out, out_stride, ntok);
 }
+
+// -----------------------------------------------------------------------------------------------------
+// Many-token form of the float matmul (batched steps, prefill) on the matrix cores.
+// v_mfma_f32_32x32x1_2b_f32 has K = 1: every output receives exactly one product per instruction, d = a*b + c with one rounding,
+// denormals kept -- bit-identical to fmaf (scripts/check_mfma_f32_k1.hip: 0 mismatches in 409 600 chains incl. 90 000 denormal
+// results).  A run of 8 such instructions on one accumulator tile IS the spec's 8-element fma chain for 64 rows x 32 tokens at
+// once, with both operands coming from plain vector registers (lane = weight row for A, lane = token for B).
+//   * weights: tiled copy FMat::wt [N/64][K/8][64 rows][8 elements] -> one contiguous 1/2 KB load per 8-element chunk;
+//   * a wave owns (64 rows, 32 tokens, one 256-element segment): 4 chains x 8 MFMAs per 32-element block, block sum
+//     (c0+c1)+(c2+c3) and segment sum on whole accumulator tiles (v_pk_add_f32);
+//   * the 8 waves of a workgroup take the 8 segments of one super-segment; segment sums meet in LDS and are added in spec order.
+// -----------------------------------------------------------------------------------------------------
+typedef float f32x32 __attribute__((ext_vector_type(32)));
+template <int TYPE> struct RawChunk { uint4 a; };
+template <> struct RawChunk<Q3_T_F32> { uint4 a, b; };
+template <int TYPE>
+__device__ __forceinline__ RawChunk<TYPE> load_raw(const char* p) {
+    RawChunk<TYPE> r;
+    r.a = *reinterpret_cast<const uint4*>(p);
+    if constexpr (TYPE == Q3_T_F32) r.b = *reinterpret_cast<const uint4*>(p + 16);
+    return r;
+}
+template <int TYPE>
+__device__ __forceinline__ void unpack_raw(const RawChunk<TYPE>& r, float* v) {
+    if constexpr (TYPE == Q3_T_F32) {
+        v[0] = __uint_as_float(r.a.x); v[1] = __uint_as_float(r.a.y); v[2] = __uint_as_float(r.a.z); v[3] = __uint_as_float(r.a.w);
+        v[4] = __uint_as_float(r.b.x); v[5] = __uint_as_float(r.b.y); v[6] = __uint_as_float(r.b.z); v[7] = __uint_as_float(r.b.w);
+    } else {
+        const uint32_t wds[4] = { r.a.x, r.a.y, r.a.z, r.a.w };
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            if constexpr (TYPE == Q3_T_BF16) { v[2 * i] = q3_bits_f32(wds[i] << 16); v[2 * i + 1] = q3_bits_f32(wds[i] & 0xFFFF0000u); }
+            else { v[2 * i] = h2f(wds[i] & 0xFFFFu); v[2 * i + 1] = h2f(wds[i] >> 16); }
+        }
+    }
+}
+constexpr int FM_TOK = 32, FM_PAD = 33; // tokens per workgroup tile; LDS row pitch (conflict-free transposed read)
+template <int TYPE>
+__global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
+                                                         int x_stride, float* __restrict__ out, int out_stride, int ntok) {
+    extern __shared__ float segsum[]; // [8 segments][64 rows][FM_PAD]
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int tile = blockIdx.x, tok0 = blockIdx.y * FM_TOK;
+    const int nseg = K >> 8;
+    constexpr size_t CH = (TYPE == Q3_T_F32 ? 32 : 16) * 64; // bytes of one 8-element chunk of a 64-row tile
+    const char* wbase = (const char*)wt + (size_t)(tile0 + tile) * (size_t)(K >> 3) * CH + (size_t)lane * (CH / 64);
+    int tok = tok0 + (lane & 31);
+    if (tok > ntok - 1) tok = ntok - 1;
+    const float* xrow = x + (size_t)tok * x_stride;
+    const int orow = threadIdx.x & 63, otok = threadIdx.x >> 6; // outputs this thread combines: (orow, otok + 8 i), i < 4
+    float y[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+    for (int ss = 0; ss * Q3_SSEG_SEGS < nseg; ss++) {
+        const int s = ss * Q3_SSEG_SEGS + wave;
+        if (s < nseg) {
+            f32x32 acc;
+#pragma unroll
+            for (int v = 0; v < 32; v++) acc[v] = 0.0f;
+            const char* wp = wbase + (size_t)s * 32 * CH;
+            const float* xp = xrow + (s << 8);
+            // weights stream from HBM (latency > one block of MFMAs): fetched two blocks ahead (one for f32 weights: register budget);
+            // activations are L2-resident: one block ahead
+            constexpr bool DEEP = TYPE != Q3_T_F32;
+            RawChunk<TYPE> raw[4], raw1[4];
+            float4 xb[8];
+#pragma unroll
+            for (int j = 0; j < 4; j++) { raw[j] = load_raw<TYPE>(wp + (size_t)j * CH); if constexpr (DEEP) raw1[j] = load_raw<TYPE>(wp + (size_t)(4 + j) * CH); }
+#pragma unroll
+            for (int j = 0; j < 8; j++) xb[j] = *reinterpret_cast<const float4*>(xp + 4 * j);
+#pragma unroll 1
+            for (int b = 0; b < 8; b++) {
+                const int b1 = b < 7 ? b + 1 : 7, b2 = b < 6 ? b + 2 : 7; // (the tail re-reads the last block; unused)
+                RawChunk<TYPE> raw2[4];
+                float4 xn[8];
+                // (activations first: vmcnt retires in issue order, so waiting for them must not also wait for the far weight block)
+#pragma unroll
+                for (int j = 0; j < 8; j++) xn[j] = *reinterpret_cast<const float4*>(xp + b1 * 32 + 4 * j);
+#pragma unroll
+                for (int j = 0; j < 4; j++) raw2[j] = load_raw<TYPE>(wp + (size_t)((DEEP ? b2 : b1) * 4 + j) * CH);
+                f32x32 p01, p23;
+#pragma unroll
+                for (int j = 0; j < 4; j++) {
+                    float wv[8];
+                    unpack_raw<TYPE>(raw[j], wv);
+                    const float xv[8] = { xb[2 * j].x, xb[2 * j].y, xb[2 * j].z, xb[2 * j].w, xb[2 * j + 1].x, xb[2 * j + 1].y, xb[2 * j + 1].z, xb[2 * j + 1].w };
+                    f32x32 c;
+#pragma unroll
+                    for (int v = 0; v < 32; v++) c[v] = 0.0f;
+#pragma unroll
+                    for (int i = 0; i < 8; i++) c = __builtin_amdgcn_mfma_f32_32x32x1f32(wv[i], xv[i], c, 0, 0, 0);
+                    if (j == 0) p01 = c; else if (j == 1) p01 = p01 + c; else if (j == 2) p23 = c; else p23 = p23 + c;
+                }
+                acc = acc + (p01 + p23);
+#pragma unroll
+                for (int j = 0; j < 4; j++) { if constexpr (DEEP) { raw[j] = raw1[j]; raw1[j] = raw2[j]; } else raw[j] = raw2[j]; }
+#pragma unroll
+                for (int j = 0; j < 8; j++) xb[j] = xn[j];
+            }
+            float* dst = segsum + (size_t)wave * 64 * FM_PAD;
+#pragma unroll
+            for (int v = 0; v < 32; v++) {
+                const int row = 32 * (v >> 4) + 8 * ((v & 15) >> 2) + 4 * (lane >> 5) + (v & 3);
+                dst[row * FM_PAD + (lane & 31)] = acc[v];
+            }
+        }
+        __syncthreads();
+        const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            float S = 0.0f;
+            for (int sg = 0; sg < nsl; sg++) {
+                const float a = segsum[((size_t)sg * 64 + orow) * FM_PAD + otok + 8 * i];
+                S = sg == 0 ? a : S + a;
+            }
+            y[i] = ss == 0 ? S : y[i] + S;
+        }
+        __syncthreads();
+    }
+    const int r = tile * 64 + orow;
+#pragma unroll
+    for (int i = 0; i < 4; i++) {
+        const int t = tok0 + otok + 8 * i;
+        if (t < ntok && r < nrows) out[(size_t)t * out_stride + r] = y[i];
+    }
+}
+// Few-token form (batched decode steps: 12..64 tokens): v_mfma_f32_16x16x1_4b_f32 runs the FOUR chains of a 32-element block as its
+// four blocks -- lane (u, i) feeds weight w[row i][8u + step], lane (u, j) feeds x[token j][8u + step] -- so after 8 instructions
+// registers v, v+4, v+8, v+12 of a lane hold c0..c3 of the same output and the block sum (c0+c1)+(c2+c3) is four in-lane adds.
+// A wave owns (16 rows, 16 tokens, one segment): 64 MFMAs of 8 passes, ~50 registers -> 16x finer tasks than the 32x32 kernel,
+// which is what a 32-token step on 256 CUs needs (the 32x32 form leaves most SIMDs idle there).
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+constexpr int FS_PAD = 17;
+template <int TYPE>
+__global__ void __launch_bounds__(512) k_gemm_float_mfma16(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
+                                                           int x_stride, float* __restrict__ out, int out_stride, int ntok) {
+    __shared__ float segsum[Q3_SSEG_SEGS][16][FS_PAD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane >> 4, li = lane & 15;
+    const int rt = blockIdx.x, tok0 = blockIdx.y * 16; // 16-row tile (relative to tile0 * 4), 16-token tile
+    const int nseg = K >> 8;
+    constexpr size_t ESZ = TYPE == Q3_T_F32 ? 4 : 2;
+    constexpr size_t CH = 8 * ESZ * 64; // bytes of one 8-element chunk of a 64-row tile
+    const char* wbase = (const char*)wt + (size_t)(tile0 + (rt >> 2)) * (size_t)(K >> 3) * CH + (size_t)u * CH + (size_t)((rt & 3) * 16 + li) * 8 * ESZ;
+    int tok = tok0 + li;
+    if (tok > ntok - 1) tok = ntok - 1;
+    const float* xrow = x + (size_t)tok * x_stride + 8 * u;
+    const int orow = threadIdx.x & 15, otok = (threadIdx.x >> 4) & 15; // threads < 256 combine one output each
+    float y = 0.0f;
+    for (int ss = 0; ss * Q3_SSEG_SEGS < nseg; ss++) {
+        const int s = ss * Q3_SSEG_SEGS + wave;
+        if (s < nseg) {
+            float acc[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const char* wp = wbase + (size_t)s * 32 * CH;
+            const float* xp = xrow + (s << 8);
+            RawChunk<TYPE> raw[3];
+            float4 xa[3][2];
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                raw[d] = load_raw<TYPE>(wp + (size_t)(4 * d) * CH);
+                xa[d][0] = *reinterpret_cast<const float4*>(xp + 32 * d); xa[d][1] = *reinterpret_cast<const float4*>(xp + 32 * d + 4);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int b2 = b < 6 ? b + 2 : 7; // (the tail re-reads the last block; unused)
+                raw[(b + 2) % 3] = load_raw<TYPE>(wp + (size_t)(4 * b2) * CH);
+                xa[(b + 2) % 3][0] = *reinterpret_cast<const float4*>(xp + 32 * b2); xa[(b + 2) % 3][1] = *reinterpret_cast<const float4*>(xp + 32 * b2 + 4);
+                float wv[8];
+                unpack_raw<TYPE>(raw[b % 3], wv);
+                const float4 x0 = xa[b % 3][0], x1 = xa[b % 3][1];
+                const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+                f32x16 c;
+#pragma unroll
+                for (int v = 0; v < 16; v++) c[v] = 0.0f;
+#pragma unroll
+                for (int i = 0; i < 8; i++) c = __builtin_amdgcn_mfma_f32_16x16x1f32(wv[i], xv[i], c, 0, 0, 0);
+#pragma unroll
+                for (int r = 0; r < 4; r++) acc[r] = acc[r] + ((c[r] + c[r + 4]) + (c[r + 8] + c[r + 12]));
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) segsum[wave][4 * u + r][li] = acc[r];
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
+            float S = 0.0f;
+            for (int sg = 0; sg < nsl; sg++) { const float a = segsum[sg][orow][otok]; S = sg == 0 ? a : S + a; }
+            y = ss == 0 ? S : y + S;
+        }
+        __syncthreads();
+    }
+    const int r = rt * 16 + orow, t = tok0 + otok;
+    if (threadIdx.x < 256 && t < ntok && r < nrows) out[(size_t)t * out_stride + r] = y;
+}
+// row-major -> tiled copy (model load): one thread per 8-element chunk
+template <int ESZ>
+__global__ void k_tile_rows(const char* __restrict__ w, char* __restrict__ wt, int N, int K) {
+    const size_t id = (size_t)blockIdx.x * blockDim.x + threadIdx.x; // ((tile * K/8) + kc) * 64 + lane
+    const size_t kc8 = (size_t)(K >> 3);
+    const size_t ntile = (size_t)(N + 63) / 64;
+    if (id >= ntile * kc8 * 64) return;
+    const int lane = (int)(id & 63); const size_t kc = (id >> 6) % kc8, tile = (id >> 6) / kc8;
+    const size_t row = tile * 64 + lane;
+    uint4 a = make_uint4(0, 0, 0, 0), b = a;
+    if (row < (size_t)N) {
+        const char* src = w + (row * K + kc * 8) * ESZ;
+        a = *reinterpret_cast<const uint4*>(src);
+        if (ESZ == 4) b = *reinterpret_cast<const uint4*>(src + 16);
+    }
+    char* dst = wt + id * 8 * ESZ;
+    *reinterpret_cast<uint4*>(dst) = a;
+    if (ESZ == 4) *reinterpret_cast<uint4*>(dst + 16) = b;
+}
+void launch_tile_float(hipStream_t st, const void* w, void* wt, int type, int N, int K) {
+    const size_t n = (size_t)((N + 63) / 64) * (K >> 3) * 64;
+    const unsigned grid = (unsigned)((n + 255) / 256);
+    if (type == Q3_T_F32) hipLaunchKernelGGL((k_tile_rows<4>), dim3(grid), dim3(256), 0, st, (const char*)w, (char*)wt, N, K);
+    else hipLaunchKernelGGL((k_tile_rows<2>), dim3(grid), dim3(256), 0, st, (const char*)w, (char*)wt, N, K);
+}
+template <int TYPE>
+static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
+    // below ~a third of the 32-token tile the GEMV form (one wave per row) is the faster one
+    static const int min_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_MIN"); return e ? atoi(e) : 12; }();
+    if (!w.wt || min_tok <= 0 || ntok < min_tok || row0 % 64 != 0 || (w.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
+    constexpr size_t lds = (size_t)Q3_SSEG_SEGS * 64 * FM_PAD * sizeof(float);
+    static const bool attr_set = [] {
+        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<TYPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        return true;
+    }();
+    (void)attr_set;
+    static const int wide_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WIDE"); return e ? atoi(e) : 96; }();
+    if (ntok < wide_tok) { // few tokens: 16 x 16 tiles, 16x more workgroups
+        dim3 grid16((nrows + 15) / 16, (ntok + 15) / 16);
+        hipLaunchKernelGGL((k_gemm_float_mfma16<TYPE>), grid16, dim3(512), 0, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+        return true;
+    }
+    dim3 grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK);
+    hipLaunchKernelGGL((k_gemm_float_mfma<TYPE>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+    return true;
+}
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
+    if (w.type == Q3_T_F32 ? gemm_float_mfma<Q3_T_F32>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok)
+        : w.type == Q3_T_F16 ? gemm_float_mfma<Q3_T_F16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok)
+                             : gemm_float_mfma<Q3_T_BF16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok)) return;
     if (w.type == Q3_T_F32) gemv_float_mt<Q3_T_F32>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
     else if (w.type == Q3_T_F16) gemv_float_mt<Q3_T_F16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);
     else gemv_float_mt<Q3_T_BF16>(st, w, row0, nrows, x, x_stride, out, out_stride, ntok);

@@ -156,6 +156,13 @@ FMat Transformer::make_fmat(const Gguf& g, const std::vector<std::string>& names
     size_t off = 0;
     for (auto& n : names) { const GgufTensor& t = g.need(n); Q3_HIP(hipMemcpy(blobs_.back().p + off, t.data, t.nbytes, hipMemcpyHostToDevice)); off += t.nbytes; }
     m.w = blobs_.back().p;
+    if (K_expect % 256 == 0) { // tiled copy for the many-token kernel (k_gemm_float_mfma)
+        const size_t esz = m.type == Q3_T_F32 ? 4 : 2;
+        blobs_.emplace_back((size_t)((m.N + 63) / 64) * 64 * K_expect * esz);
+        launch_tile_float(nullptr, m.w, blobs_.back().p, m.type, m.N, K_expect);
+        Q3_HIP(hipDeviceSynchronize());
+        m.wt = blobs_.back().p;
+    }
     return m;
 }
 
@@ -289,6 +296,10 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
                                   n_ctx_, d_mrope_.p, tm, kv, l, parts_o_.p, d, ntok);
                 if (timer) timer->end(st, (double)L.wo.bytes());
             } else {
+                if (short_attn_min_ > 0 && ntok >= short_attn_min_ && hp_.n_head == 2 * hp_.n_kv)
+                    launch_attention_short(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
+                                           rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
+                else
                 launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                                        rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
             }
@@ -325,7 +336,10 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         norm(a);
         gemv(st, L.wqkv, 0, dq + 2 * dkv, xq_.p, xd_.p, qkv_.p, dq + 2 * dkv, ntok);
         static const bool fuse_attn = [] { const char* e = std::getenv("Q3_BATCH_FUSED_ATTN"); return e && e[0] == '1'; }();
-        if (fuse_attn && fused && !same_seq_) // experiment: measured 13.4 us vs 8.0 + 4.8 us for the two-kernel form at 64 sequences
+        if (short_attn_min_ > 0 && ntok >= short_attn_min_ && !same_seq_ && hp_.n_head == 2 * hp_.n_kv)
+            launch_attention_short(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                                   n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
+        else if (fuse_attn && fused && !same_seq_) // experiment: measured 13.4 us vs 8.0 + 4.8 us for the two-kernel form at 64 sequences
             launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
                                    n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
         else {

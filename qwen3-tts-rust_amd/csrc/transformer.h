@@ -43,6 +43,8 @@ public:
     void set_same_seq_tokens(bool v) { same_seq_ = v; }
     // every cached context of this model stays <= 64 positions (the code predictor): fold attention into the o-proj launch
     void set_short_context(bool v) { short_ctx_ = v; }
+    // sequences never exceed 64 positions (one KV page): steps of at least `min_tok` tokens use the single-wave attention kernel
+    void set_short_attention(int min_tok) { short_attn_min_ = min_tok; }
     // largest token count that still takes the 5-launch fused layer path (its GEMVs re-read the weights once per 4-8 token tile,
     // which is fine for a model whose weights stay cache-resident, i.e. the code predictor)
     void set_fused_max_tokens(int n) { fused_max_tok_ = n; }
@@ -76,7 +78,7 @@ private:
     DevBuf<int32_t> d_mrope_;
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
-    bool same_seq_ = false; bool short_ctx_ = false; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
+    bool same_seq_ = false; bool short_ctx_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
     std::map<const uint8_t*, uint8_t*> mat_meta_, mat_types_;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;

@@ -61,7 +61,7 @@ SYMBOLS = [
     "q3tts_prompt_build_clone", "q3tts_sampler_new", "q3tts_sampler_free", "q3tts_sampler_sample", "q3tts_chunker_new",
     "q3tts_chunker_free", "q3tts_chunker_push", "q3tts_decoder_create", "q3tts_decoder_destroy", "q3tts_decoder_samples_per_frame",
     "q3tts_decoder_reset", "q3tts_decoder_decode", "q3tts_mel_frames", "q3tts_mel", "q3tts_tf_open", "q3tts_tf_close",
-    "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
+    "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_matmul_float", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
     "q3tts_op_argmax", "q3tts_op_project", "q3tts_op_sample", "q3tts_submit", "q3tts_poll", "q3tts_fetch", "q3tts_wait",
     "q3tts_release", "q3tts_decoder_create_ex", "q3tts_decoder_decode_group", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
 ]
@@ -129,6 +129,7 @@ def lib():
         L.q3tts_tf_clear.argtypes = [C.c_void_p]
         L.q3tts_tf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.q3tts_op_gemv_q8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.q3tts_op_matmul_float.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.q3tts_op_rmsnorm_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.q3tts_op_swiglu_quant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
         L.q3tts_op_argmax.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p]
@@ -458,6 +459,16 @@ def op_gemv_q8(w_raw, n, k, xq, xd, lpr=0):
     w_raw = np.ascontiguousarray(w_raw, np.uint8)
     y = np.zeros((xq.shape[0], n), np.float32)
     _chk(lib().q3tts_op_gemv_q8(_p(w_raw), n, k, _p(xq), _p(xd), xq.shape[0], _p(y), lpr))
+    return y
+
+
+def op_matmul_float(w_raw, ggml_type, n, k, x, row0=0, nrows=None):
+    """w_raw: the row-major weight bytes (f32 / f16 / bf16 per ggml_type); x [ntok][k] f32 -> y [ntok][nrows] f32"""
+    nrows = n - row0 if nrows is None else nrows
+    w_raw = np.ascontiguousarray(w_raw)
+    x = np.ascontiguousarray(x, np.float32)
+    y = np.zeros((x.shape[0], nrows), np.float32)
+    _chk(lib().q3tts_op_matmul_float(_p(w_raw), ggml_type, n, k, row0, nrows, _p(x), x.shape[0], _p(y)))
     return y
 
 

@@ -6,7 +6,7 @@ import statistics
 import sys
 
 src, dst = sys.argv[1], sys.argv[2]
-f = glob.glob(src + "/*/*_kernel_trace.csv")[0]
+f = (glob.glob(src + "/*/*_kernel_trace.csv") + glob.glob(src + "/*_kernel_trace.csv"))[0]
 agg = collections.defaultdict(list)
 for r in csv.DictReader(open(f)):
     name = r["Kernel_Name"].replace("void q3::", "").replace("q3::", "").split("(")[0]

@@ -44,6 +44,38 @@ def test_gemv_q8_bit_exact(gpu, oracle, n, k, ntok):
         assert np.array_equal(_bits(gpu.op_gemv_q8(raw, n, k, xq, xd, lpr)), _bits(yo)), lpr
 
 
+def _float_weights(rng, ty, n, k):
+    w = (rng.standard_normal((n, k)) * 0.05).astype(np.float32)
+    w[rng.integers(0, n, 8), rng.integers(0, k, 8)] = 0.0
+    if ty == 0:
+        return w
+    if ty == 1:
+        return w.astype(np.float16)
+    u = w.view(np.uint32)
+    return ((u + 0x7FFF + ((u >> 16) & 1)) >> 16).astype(np.uint16)   # bf16, round to nearest even
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("ty,n,k,ntok", [(30, 192, 2048, 32), (30, 100, 1024, 13), (30, 64, 6144, 45), (30, 130, 3072, 64), (1, 128, 2048, 33),
+                                         (0, 70, 1024, 12), (30, 64, 2048, 3), (30, 256, 2048, 200)])
+def test_matmul_float_bit_exact(gpu, oracle, ty, n, k, ntok):
+    """float-weight matmul (spec S3 float form): the matrix-core kernel (K = 1 f32 MFMA chains, ntok >= 12) and the one-wave-per-row
+    GEMV (fewer tokens) against the oracle's row_dot, bit for bit; also a 64-aligned row sub-range as the predictor head uses."""
+    rng = np.random.default_rng(n * 7 + k + ntok)
+    w = _float_weights(rng, ty, n, k)
+    x = (rng.standard_normal((ntok, k)) * rng.uniform(0.1, 4)).astype(np.float32)
+    x[0, :64] = 1e-30 * rng.standard_normal(64)            # products and partial sums in the denormal range
+    yo = np.zeros((ntok, n), np.float32)
+    L = oracle.lib()
+    for t in range(ntok):
+        L.q3o_matvec(ty, w.ctypes.data, n, k, None, None, x[t].ctypes.data, yo[t].ctypes.data)
+    yg = gpu.op_matmul_float(w, ty, n, k, x)
+    assert np.array_equal(_bits(yg), _bits(yo))
+    if n > 64:
+        yg2 = gpu.op_matmul_float(w, ty, n, k, x, row0=64, nrows=n - 64)
+        assert np.array_equal(_bits(yg2), _bits(yo[:, 64:]))
+
+
 @pytest.mark.parametrize("d", [256, 1024, 2048])
 def test_rmsnorm_quant_bit_exact(gpu, oracle, d):
     rng = np.random.default_rng(d)
