@@ -131,7 +131,8 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
                             int ntok);
 void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
-                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok);
+                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok,
+                            float* att = nullptr /*optional f32 rows [ntok][n_head*128]*/);
 void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
                        const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                        const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok);

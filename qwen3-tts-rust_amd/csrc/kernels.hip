@@ -997,9 +997,9 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict_
             for (int v = 0; v < 32; v++) acc[v] = 0.0f;
             const char* wp = wbase + (size_t)s * 32 * CH;
             const float* xp = xrow + (s << 8);
-            // weights stream from HBM (latency > one block of MFMAs): fetched two blocks ahead (one for f32 weights: register budget);
-            // activations are L2-resident: one block ahead
-            constexpr bool DEEP = TYPE != Q3_T_F32;
+            // operands are fetched one block ahead.  Two blocks ahead for the weights (DEEP) measured slower on MI355X: 200 vs 157 us
+            // for the 12288 x 2048 x 256-token prefill GEMM -- the extra live registers cost more than the latency they hide.
+            constexpr bool DEEP = false;
             RawChunk<TYPE> raw[4], raw1[4];
             float4 xb[8];
 #pragma unroll
@@ -1157,8 +1157,9 @@ void launch_tile_float(hipStream_t st, const void* w, void* wt, int type, int N,
 }
 template <int TYPE>
 static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {
-    // below ~a third of the 32-token tile the GEMV form (one wave per row) is the faster one
-    static const int min_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_MIN"); return e ? atoi(e) : 12; }();
+    // measured on MI355X (bf16, AR step ms): 2 sequences 5.58 vs 6.15 (GEMV), 8 sequences 6.02 vs 11.87 -- the matrix-core form wins
+    // from two tokens up even though a 16-token tile is then mostly padding (the step is latency-, not throughput-bound)
+    static const int min_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_MIN"); return e ? atoi(e) : 2; }();
     if (!w.wt || min_tok <= 0 || ntok < min_tok || row0 % 64 != 0 || (w.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
     constexpr size_t lds = (size_t)Q3_SSEG_SEGS * 64 * FM_PAD * sizeof(float);
     static const bool attr_set = [] {

@@ -760,7 +760,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
                                                         const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w, float eps,
                                                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int n_ctx,
                                                         const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv, int layer,
-                                                        int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+                                                        int8_t* __restrict__ aq, uint16_t* __restrict__ ad, float* __restrict__ att) {
     __shared__ __attribute__((aligned(16))) float q_s[2][128];
     __shared__ __attribute__((aligned(16))) uint16_t kcur_s[128];
     __shared__ __attribute__((aligned(16))) uint16_t vcur_s[128];
@@ -866,6 +866,11 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
     const int dq = n_head * 128;
 #pragma unroll
     for (int hh = 0; hh < 2; hh++) {
+        if (att && jj == 0) { // float-weight models consume the f32 rows
+            float* o = att + (size_t)tok * dq + (size_t)(2 * kvh + hh) * 128 + dc * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(y[hh][0], y[hh][1], y[hh][2], y[hh][3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[hh][4], y[hh][5], y[hh][6], y[hh][7]);
+        }
         float amax = 0.0f;
 #pragma unroll
         for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
@@ -887,9 +892,9 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
 }
 void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
-                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok) {
+                            const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok, float* att) {
     hipLaunchKernelGGL(k_attention_short, dim3(n_kv, ntok), dim3(64), 0, st, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, rope_cos,
-                       rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad);
+                       rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad, att);
 }
 
 // ===================================================================================================

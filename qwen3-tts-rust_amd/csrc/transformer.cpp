@@ -376,7 +376,11 @@ void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const
         NormArgs a{};
         a.h_in = h_in; a.h_stride = h_stride; a.idx_keys = idx_keys; a.idx_stride = idx_stride; a.parts = parts; a.nparts = parts ? 1 : 0; a.parts_stride = d;
         a.h_out = h_.p; a.g = g; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p; a.xn_out = xn; // int8 copy unused in float mode
-        launch_rmsnorm_quant(st, a, ntok);
+        if (ntok <= 8) { launch_rmsnorm_quant(st, a, ntok); return; }
+        NormPro p{}; // batched steps: workgroup-per-token norm kernel (same arithmetic)
+        p.h_in = a.h_in; p.h_stride = a.h_stride; p.idx_keys = a.idx_keys; p.idx_stride = a.idx_stride; p.parts = a.parts; p.nparts = a.nparts;
+        p.parts_stride = a.parts_stride; p.parts_slab = (size_t)ntok * a.parts_stride; p.h_out = a.h_out; p.g = a.g; p.eps = a.eps; p.xn_out = a.xn_out;
+        launch_rmsnorm_quant_wg(st, p, a.d, a.xq, a.xd, ntok);
     };
     auto fgemv = [&](const FMat& w, const float* x, int xs, float* out, int os) {
         if (timer) timer->begin(st);
@@ -388,9 +392,14 @@ void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const
         if (l == 0) norm(in.x, in.x_stride, in.idx_keys, in.idx_stride, nullptr, L.attn_norm, xnf_.p);
         else norm(h_.p, d, nullptr, 0, parts_d_.p, L.attn_norm, xnf_.p);
         fgemv(L.fqkv, xnf_.p, d, qkv_.p, dq + 2 * dkv);
-        launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
-                              n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
-        launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, attf_.p, aq_.p, ad_.p, ntok);
+        if (short_attn_min_ > 0 && ntok >= short_attn_min_ && !same_seq_ && hp_.n_head == 2 * hp_.n_kv)
+            launch_attention_short(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                                   n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok, attf_.p);
+        else {
+            launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
+                                  n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
+            launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, attf_.p, aq_.p, ad_.p, ntok);
+        }
         fgemv(L.fo, attf_.p, dq, parts_o_.p, d);
         norm(h_.p, d, nullptr, 0, parts_o_.p, L.ffn_norm, xnf_.p);
         fgemv(L.fgu, xnf_.p, d, gu_.p, 2 * ff);
