@@ -234,10 +234,17 @@ def main():
         }
         if args.batch > 1:
             # batched steps run the weight-streaming GEMM kernels (k_gemm_q8_mfma / k_gemm_q8_tok); the instrumented family is the line
-            fam_name = "q3::k_gemv_float" if args.quant in ("bf16", "f16", "f32") else "q3::k_gemm_q8_mfma + k_gemv_q8*"
+            fam_name = "q3::k_gemm_float_mfma16 / k_gemm_float_mfma (f32 MFMA, K = 1)" if args.quant in ("bf16", "f16", "f32") else "q3::k_gemm_q8_mfma + k_gemv_q8*"
             out["roofline"].update({"kernel": "%s family (batched step; %d launches)" % (fam_name, fam_n), "achieved": gemv_gbs,
                                     "frac": gemv_gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1),
                                     "bytes_per_launch": fam_bytes / max(fam_n, 1), "traffic": None})
+            if args.quant in ("bf16", "f16", "f32"):
+                # float weights: f32 activations x f32-widened weights on the K = 1 f32 MFMA (exact fma chains) -- at `batch` tokens per launch
+                # the matrix pipe, not HBM, is the nearer roof: 2 flops per weight element per token against the 157.3 TFLOP/s f32 MFMA peak
+                esz = 4 if args.quant == "f32" else 2
+                tfl = 2.0 * (fam_bytes / esz) * args.batch / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
+                out["roofline"].update({"bound": "mfma", "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
+                                        "hbm_view": {"achieved_gbs": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS}})
         log("instrumented leg done")
         if world == 1 and not args.no_cpu_baseline:
             try:
