@@ -142,6 +142,19 @@ def main():
             vr = np.random.default_rng(1000 + v)
             voices.append(((spk_emb * (1.0 - 0.1 * v) + 0.01 * vr.standard_normal(2048)).astype(np.float32), vr.integers(0, 2048, 62 * 16).astype(np.int32),
                            vr.integers(0, 4000, 24).astype(np.int32)))
+        # reference-audio front end (row a16, onnx.rs:167-320): log-mel of a seeded 5 s chirp + noise per voice on the device.  The codec /
+        # speaker encoder graphs that would consume it are not in the container (SURVEY 8a row a17 -> next row f-2), so the reference
+        # codes and speaker embeddings above stay synthetic; the mel time is reported, not hidden.
+        import q3tts as _q
+        tt = np.arange(5 * 24000) / 24000.0
+        ref_audio = [(0.4 * np.sin(2 * np.pi * (200 + 600 * v + 2500 * tt) * tt) + 0.02 * np.random.default_rng(7 + v).standard_normal(tt.size)).astype(np.float32)
+                     for v in range(4)]
+        _q.mel(ref_audio[0])  # warm-up (filter bank + twiddles are built on first use)
+        t0 = time.perf_counter()
+        mels = [_q.mel(a) for a in ref_audio]
+        clone_info = {"ref_audio_s_per_voice": 5.0, "voices": 4, "mel_frames_per_voice": int(mels[0].shape[0]),
+                      "mel_ms_per_voice_incl_pcie": 1e3 * (time.perf_counter() - t0) / 4,
+                      "encoders": "absent from the container (SURVEY 8a a17 / 8f f-2): reference codes and speaker embeddings are seeded synthetic"}
         prompts = []
         for i in range(n_req):
             se, rc, rt = voices[i % 4]
@@ -232,6 +245,8 @@ def main():
                          "family_all_gemv": {"achieved": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS, "launches": fam_n,
                                              "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1)}},
         }
+        if args.clone:
+            out["config"]["ref_audio_front_end"] = clone_info
         if args.batch > 1:
             # batched steps run the weight-streaming GEMM kernels (k_gemm_q8_mfma / k_gemm_q8_tok); the instrumented family is the line
             fam_name = "q3::k_gemm_float_mfma16 / k_gemm_float_mfma (f32 MFMA, K = 1)" if args.quant in ("bf16", "f16", "f32") else "q3::k_gemm_q8_mfma + k_gemv_q8*"
