@@ -101,6 +101,7 @@ void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
 // w: row-major [N][K]; wt: the same elements tiled [ceil(N/64)][K/8][64][8] for k_gemm_float_mfma (rows past N are zero)
 struct FMat { const void* w = nullptr; const void* wt = nullptr; int type = 0; int N = 0, K = 0; size_t bytes() const { return (size_t)N * K * (type == 0 ? 4 : 2); } };
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok);
+bool launch_gateup_float(hipStream_t st, const FMat& wgu, int ff, const float* x, int x_stride, float* act, int ntok);
 void launch_tile_float(hipStream_t st, const void* w, void* wt, int type, int N, int K);
 void launch_swiglu_f32(hipStream_t st, const float* gu, int ff, float* out, int ntok);
 

@@ -1130,6 +1130,82 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma16(const void* __restric
     const int r = rt * 16 + orow, t = tok0 + otok;
     if (threadIdx.x < 256 && t < ntok && r < nrows) out[(size_t)t * out_stride + r] = y;
 }
+// Gate/up pair of the float-weight MLP in one launch: a workgroup computes the 16 gate rows AND the 16 matching up rows for its 16
+// tokens (the x operand is loaded once for both), combines the segment sums in spec order and writes silu(g)*u (q3_swiglu) -- the
+// [ntok][2 ff] gate/up round trip and the separate SwiGLU launch of the unfused form disappear.  Same arithmetic per output.
+template <int TYPE>
+__global__ void __launch_bounds__(512) k_gateup_float_mfma16(const void* __restrict__ wt, int K, int ff, const float* __restrict__ x, int x_stride,
+                                                             float* __restrict__ act, int ntok) {
+    __shared__ float segsum[2][Q3_SSEG_SEGS][16][FS_PAD];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int u = lane >> 4, li = lane & 15;
+    const int rt = blockIdx.x, tok0 = blockIdx.y * 16;
+    const int nseg = K >> 8;
+    constexpr size_t ESZ = TYPE == Q3_T_F32 ? 4 : 2;
+    constexpr size_t CH = 8 * ESZ * 64;
+    const int rtu = rt + (ff >> 4); // the up rows' 16-row tile
+    const char* wg = (const char*)wt + (size_t)(rt >> 2) * (size_t)(K >> 3) * CH + (size_t)u * CH + (size_t)((rt & 3) * 16 + li) * 8 * ESZ;
+    const char* wu = (const char*)wt + (size_t)(rtu >> 2) * (size_t)(K >> 3) * CH + (size_t)u * CH + (size_t)((rtu & 3) * 16 + li) * 8 * ESZ;
+    int tok = tok0 + li;
+    if (tok > ntok - 1) tok = ntok - 1;
+    const float* xrow = x + (size_t)tok * x_stride + 8 * u;
+    const int orow = threadIdx.x & 15, otok = (threadIdx.x >> 4) & 15;
+    float yg = 0.0f, yu = 0.0f;
+    for (int ss = 0; ss * Q3_SSEG_SEGS < nseg; ss++) {
+        const int s = ss * Q3_SSEG_SEGS + wave;
+        if (s < nseg) {
+            float ag[4] = { 0.0f, 0.0f, 0.0f, 0.0f }, au[4] = { 0.0f, 0.0f, 0.0f, 0.0f };
+            const char* pg = wg + (size_t)s * 32 * CH;
+            const char* pu = wu + (size_t)s * 32 * CH;
+            const float* xp = xrow + (s << 8);
+            RawChunk<TYPE> rg[3], ru[3];
+            float4 xa[3][2];
+#pragma unroll
+            for (int d = 0; d < 2; d++) {
+                rg[d] = load_raw<TYPE>(pg + (size_t)(4 * d) * CH); ru[d] = load_raw<TYPE>(pu + (size_t)(4 * d) * CH);
+                xa[d][0] = *reinterpret_cast<const float4*>(xp + 32 * d); xa[d][1] = *reinterpret_cast<const float4*>(xp + 32 * d + 4);
+            }
+#pragma unroll
+            for (int b = 0; b < 8; b++) {
+                const int b2 = b < 6 ? b + 2 : 7;
+                rg[(b + 2) % 3] = load_raw<TYPE>(pg + (size_t)(4 * b2) * CH); ru[(b + 2) % 3] = load_raw<TYPE>(pu + (size_t)(4 * b2) * CH);
+                xa[(b + 2) % 3][0] = *reinterpret_cast<const float4*>(xp + 32 * b2); xa[(b + 2) % 3][1] = *reinterpret_cast<const float4*>(xp + 32 * b2 + 4);
+                float wgv[8], wuv[8];
+                unpack_raw<TYPE>(rg[b % 3], wgv); unpack_raw<TYPE>(ru[b % 3], wuv);
+                const float4 x0 = xa[b % 3][0], x1 = xa[b % 3][1];
+                const float xv[8] = { x0.x, x0.y, x0.z, x0.w, x1.x, x1.y, x1.z, x1.w };
+                f32x16 cg, cu;
+#pragma unroll
+                for (int v = 0; v < 16; v++) { cg[v] = 0.0f; cu[v] = 0.0f; }
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    cg = __builtin_amdgcn_mfma_f32_16x16x1f32(wgv[i], xv[i], cg, 0, 0, 0);
+                    cu = __builtin_amdgcn_mfma_f32_16x16x1f32(wuv[i], xv[i], cu, 0, 0, 0);
+                }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    ag[r] = ag[r] + ((cg[r] + cg[r + 4]) + (cg[r + 8] + cg[r + 12]));
+                    au[r] = au[r] + ((cu[r] + cu[r + 4]) + (cu[r + 8] + cu[r + 12]));
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < 4; r++) { segsum[0][wave][4 * u + r][li] = ag[r]; segsum[1][wave][4 * u + r][li] = au[r]; }
+        }
+        __syncthreads();
+        if (threadIdx.x < 256) {
+            const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
+            float Sg = 0.0f, Su = 0.0f;
+            for (int sg = 0; sg < nsl; sg++) {
+                const float a = segsum[0][sg][orow][otok], c = segsum[1][sg][orow][otok];
+                Sg = sg == 0 ? a : Sg + a; Su = sg == 0 ? c : Su + c;
+            }
+            yg = ss == 0 ? Sg : yg + Sg; yu = ss == 0 ? Su : yu + Su;
+        }
+        __syncthreads();
+    }
+    const int r = rt * 16 + orow, t = tok0 + otok;
+    if (threadIdx.x < 256 && t < ntok && r < ff) act[(size_t)t * ff + r] = q3_swiglu(yg, yu);
+}
 // row-major -> tiled copy (model load): one thread per 8-element chunk
 template <int ESZ>
 __global__ void k_tile_rows(const char* __restrict__ w, char* __restrict__ wt, int N, int K) {
@@ -1175,6 +1251,16 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
     }
     dim3 grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK);
     hipLaunchKernelGGL((k_gemm_float_mfma<TYPE>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+    return true;
+}
+// fused gate/up + SwiGLU for batched steps; false = not applicable (caller runs the matmul and k_swiglu_f32)
+bool launch_gateup_float(hipStream_t st, const FMat& wgu, int ff, const float* x, int x_stride, float* act, int ntok) {
+    static const int max_tok = [] { const char* e = std::getenv("Q3_FLOAT_GU_FUSED_MAX"); return e ? atoi(e) : 95; }();
+    if (!wgu.wt || ntok < 2 || ntok > max_tok || wgu.N != 2 * ff || (ff & 15) != 0 || (wgu.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
+    dim3 grid(ff / 16, (ntok + 15) / 16);
+    if (wgu.type == Q3_T_F32) hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_F32>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
+    else if (wgu.type == Q3_T_F16) hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_F16>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
+    else hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_BF16>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
     return true;
 }
 void launch_gemv_float(hipStream_t st, const FMat& w, int row0, int nrows, const float* x, int x_stride, float* out, int out_stride, int ntok) {

@@ -402,8 +402,13 @@ void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const
         }
         fgemv(L.fo, attf_.p, dq, parts_o_.p, d);
         norm(h_.p, d, nullptr, 0, parts_o_.p, L.ffn_norm, xnf_.p);
-        fgemv(L.fgu, xnf_.p, d, gu_.p, 2 * ff);
-        launch_swiglu_f32(st, gu_.p, ff, actf_.p, ntok);
+        if (timer) timer->begin(st);
+        const bool gu_fused = launch_gateup_float(st, L.fgu, ff, xnf_.p, d, actf_.p, ntok);
+        if (timer && gu_fused) timer->end(st, (double)L.fgu.bytes()); // an unmatched begin() is simply re-recorded by the next one
+        if (!gu_fused) {
+            fgemv(L.fgu, xnf_.p, d, gu_.p, 2 * ff);
+            launch_swiglu_f32(st, gu_.p, ff, actf_.p, ntok);
+        }
         fgemv(L.fdown, actf_.p, ff, parts_d_.p, d);
     }
     norm(h_.p, d, nullptr, 0, parts_d_.p, output_norm_, hidden_out ? hidden_out : hid_.p);
