@@ -950,6 +950,17 @@ static void gemv_float_mt(hipStream_t st, const FMat& w, int row0, int nrows, co
 //     (c0+c1)+(c2+c3) and segment sum on whole accumulator tiles (v_pk_add_f32);
 //   * the 8 waves of a workgroup take the 8 segments of one super-segment; segment sums meet in LDS and are added in spec order.
 // -----------------------------------------------------------------------------------------------------
+// XCD-aware tile order for the matrix-core float kernels: workgroups are dealt round-robin to the 8 XCDs (each with its own L2), so the
+// token tiles that share one weight tile are given ids that are congruent mod 8 and consecutive on that XCD -- the weight tile is then
+// fetched into ONE L2 once and hit by the following token tiles, instead of being fetched by up to 8 L2s (or evicted in between).
+//   id -> xcd = id % 8, slot = id / 8;  row tile = (slot / n_tok_tiles) * 8 + xcd;  token tile = slot % n_tok_tiles
+__device__ __forceinline__ bool xcd_tile(int n_row_tiles, int n_tok_tiles, int* row_tile, int* tok_tile) {
+    const int id = blockIdx.x, xcd = id & 7, slot = id >> 3;
+    *row_tile = (slot / n_tok_tiles) * 8 + xcd;
+    *tok_tile = slot % n_tok_tiles;
+    return *row_tile < n_row_tiles;
+}
+static inline unsigned xcd_grid(int n_row_tiles, int n_tok_tiles) { return (unsigned)(((n_row_tiles + 7) / 8) * 8 * n_tok_tiles); }
 typedef float f32x32 __attribute__((ext_vector_type(32)));
 template <int TYPE> struct RawChunk { uint4 a; };
 template <> struct RawChunk<Q3_T_F32> { uint4 a, b; };
@@ -980,7 +991,9 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict_
                                                          int x_stride, float* __restrict__ out, int out_stride, int ntok) {
     extern __shared__ float segsum[]; // [8 segments][64 rows][FM_PAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int tile = blockIdx.x, tok0 = blockIdx.y * FM_TOK;
+    int tile, tt;
+    if (!xcd_tile((nrows + 63) >> 6, (ntok + FM_TOK - 1) / FM_TOK, &tile, &tt)) return; // (whole workgroup: no barrier is skipped)
+    const int tok0 = tt * FM_TOK;
     const int nseg = K >> 8;
     constexpr size_t CH = (TYPE == Q3_T_F32 ? 32 : 16) * 64; // bytes of one 8-element chunk of a 64-row tile
     const char* wbase = (const char*)wt + (size_t)(tile0 + tile) * (size_t)(K >> 3) * CH + (size_t)lane * (CH / 64);
@@ -1075,7 +1088,9 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma16(const void* __restric
     __shared__ float segsum[Q3_SSEG_SEGS][16][FS_PAD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane >> 4, li = lane & 15;
-    const int rt = blockIdx.x, tok0 = blockIdx.y * 16; // 16-row tile (relative to tile0 * 4), 16-token tile
+    int rt, tt; // 16-row tile (relative to tile0 * 4), 16-token tile
+    if (!xcd_tile((nrows + 15) >> 4, (ntok + 15) >> 4, &rt, &tt)) return;
+    const int tok0 = tt * 16;
     const int nseg = K >> 8;
     constexpr size_t ESZ = TYPE == Q3_T_F32 ? 4 : 2;
     constexpr size_t CH = 8 * ESZ * 64; // bytes of one 8-element chunk of a 64-row tile
@@ -1139,7 +1154,9 @@ __global__ void __launch_bounds__(512) k_gateup_float_mfma16(const void* __restr
     __shared__ float segsum[2][Q3_SSEG_SEGS][16][FS_PAD];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int u = lane >> 4, li = lane & 15;
-    const int rt = blockIdx.x, tok0 = blockIdx.y * 16;
+    int rt, tt;
+    if (!xcd_tile(ff >> 4, (ntok + 15) >> 4, &rt, &tt)) return;
+    const int tok0 = tt * 16;
     const int nseg = K >> 8;
     constexpr size_t ESZ = TYPE == Q3_T_F32 ? 4 : 2;
     constexpr size_t CH = 8 * ESZ * 64;
@@ -1245,11 +1262,11 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
     (void)attr_set;
     static const int wide_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WIDE"); return e ? atoi(e) : 96; }();
     if (ntok < wide_tok) { // few tokens: 16 x 16 tiles, 16x more workgroups
-        dim3 grid16((nrows + 15) / 16, (ntok + 15) / 16);
+        dim3 grid16(xcd_grid((nrows + 15) / 16, (ntok + 15) / 16));
         hipLaunchKernelGGL((k_gemm_float_mfma16<TYPE>), grid16, dim3(512), 0, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
         return true;
     }
-    dim3 grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK);
+    dim3 grid(xcd_grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK));
     hipLaunchKernelGGL((k_gemm_float_mfma<TYPE>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
     return true;
 }
@@ -1257,7 +1274,7 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
 bool launch_gateup_float(hipStream_t st, const FMat& wgu, int ff, const float* x, int x_stride, float* act, int ntok) {
     static const int max_tok = [] { const char* e = std::getenv("Q3_FLOAT_GU_FUSED_MAX"); return e ? atoi(e) : 95; }();
     if (!wgu.wt || ntok < 2 || ntok > max_tok || wgu.N != 2 * ff || (ff & 15) != 0 || (wgu.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
-    dim3 grid(ff / 16, (ntok + 15) / 16);
+    dim3 grid(xcd_grid(ff / 16, (ntok + 15) / 16));
     if (wgu.type == Q3_T_F32) hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_F32>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
     else if (wgu.type == Q3_T_F16) hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_F16>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
     else hipLaunchKernelGGL((k_gateup_float_mfma16<Q3_T_BF16>), grid, dim3(512), 0, st, wgu.wt, wgu.K, ff, x, x_stride, act, ntok);
