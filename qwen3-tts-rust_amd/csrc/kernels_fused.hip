@@ -753,19 +753,24 @@ void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* 
 }
 
 // ===================================================================================================
-// Single-wave attention for sequences of at most 64 cached positions (the code predictor: <= 17): one wave per (token, kv head)
-// handles both q heads of the group, K rows live in registers, no workgroup barrier.  Same arithmetic as k_attention_fused (spec S7).
+// Single-wave attention for sequences of at most 64 cached positions (the code predictor: <= 17): no workgroup barrier, K rows and the
+// cached V rows live in registers (both fetched before the prologue's arithmetic).  HPW = q heads per wave: 2 = one wave per (token,
+// kv head) serves both q heads of the group (fewest waves: wide steps); 1 = one wave per q head, the kv head's K/V row computed by both
+// waves of the pair and written by the even one (half the serial work per wave: narrow steps).  Same arithmetic as k_attention_fused (S7).
 // ===================================================================================================
+template <int HPW>
 __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict__ qkv, int qkv_stride, int n_head, int n_kv,
                                                         const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w, float eps,
                                                         const float* __restrict__ rope_cos, const float* __restrict__ rope_sin, int n_ctx,
                                                         const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv, int layer,
                                                         int8_t* __restrict__ aq, uint16_t* __restrict__ ad, float* __restrict__ att) {
-    __shared__ __attribute__((aligned(16))) float q_s[2][128];
+    __shared__ __attribute__((aligned(16))) float q_s[HPW][128];
     __shared__ __attribute__((aligned(16))) uint16_t kcur_s[128];
     __shared__ __attribute__((aligned(16))) uint16_t vcur_s[128];
-    __shared__ float p_s[2][64];
-    const int kvh = blockIdx.x, tok = blockIdx.y, lane = threadIdx.x;
+    __shared__ float p_s[HPW][64];
+    const int kvh = HPW == 2 ? blockIdx.x : blockIdx.x >> 1, h0 = HPW == 2 ? 2 * blockIdx.x : blockIdx.x; // first q head of this wave
+    const bool writer = HPW == 2 || (blockIdx.x & 1) == 0;
+    const int tok = blockIdx.y, lane = threadIdx.x;
     const float scale = 0.08838834764831845f;
     const int jj = lane >> 4, dc = lane & 15;
     const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
@@ -773,9 +778,16 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
     const int page = kv.page_of(seq, 0);
     const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
     const uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
-    uint4 kreg[16];
+    uint4 kreg[16], vreg[4][4];
 #pragma unroll
     for (int d8 = 0; d8 < 16; d8++) kreg[d8] = (lane < slot) ? *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8) : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int ww = 0; ww < 4; ww++)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const int jl = 16 * u + 4 * ww + jj;
+            vreg[ww][u] = (jl < slot) ? *reinterpret_cast<const uint4*>(Vb + jl * 128 + dc * 8) : make_uint4(0, 0, 0, 0);
+        }
     int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
     int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
     if (pp < 0) pp = 0;
@@ -783,9 +795,9 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
     const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
     const float* tv = qkv + (size_t)tok * qkv_stride;
 #pragma unroll
-    for (int which = 0; which < 3; which++) {
-        const float* vec = tv + (which < 2 ? (size_t)(2 * kvh + which) * 128 : (size_t)(n_head + kvh) * 128);
-        const float* wn = which < 2 ? q_norm_w : k_norm_w;
+    for (int which = 0; which < HPW + 1; which++) { // q heads, then k
+        const float* vec = tv + (which < HPW ? (size_t)(h0 + which) * 128 : (size_t)(n_head + kvh) * 128);
+        const float* wn = which < HPW ? q_norm_w : k_norm_w;
         const float x1 = vec[lane], x2 = vec[lane + 64];
         float p = x1 * x1;
         p = q3_fmaf(x2, x2, p);
@@ -795,25 +807,31 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
         const float y1 = (x1 * sc2) * wn[lane], y2 = (x2 * sc2) * wn[lane + 64];
         float o1, o2;
         q3_rope_pair(y1, y2, cs, sn, &o1, &o2);
-        if (which < 2) { q_s[which][lane] = o1; q_s[which][lane + 64] = o2; }
+        if (which < HPW) { q_s[which][lane] = o1; q_s[which][lane + 64] = o2; }
         else {
             const uint16_t k1 = f2h(o1), k2 = f2h(o2);
             kcur_s[lane] = k1; kcur_s[lane + 64] = k2;
-            uint16_t* Kw = kv.k + (size_t)page * kv.page_stride() + head_off;
-            Kw[((lane >> 3) * 64 + slot) * 8 + (lane & 7)] = k1;
-            Kw[(((lane + 64) >> 3) * 64 + slot) * 8 + (lane & 7)] = k2;
+            if (writer) {
+                uint16_t* Kw = kv.k + (size_t)page * kv.page_stride() + head_off;
+                Kw[((lane >> 3) * 64 + slot) * 8 + (lane & 7)] = k1;
+                Kw[(((lane + 64) >> 3) * 64 + slot) * 8 + (lane & 7)] = k2;
+            }
         }
     }
     {
         const float* vec = tv + (size_t)(n_head + n_kv + kvh) * 128;
         const uint16_t v1 = f2h(vec[lane]), v2 = f2h(vec[lane + 64]);
         vcur_s[lane] = v1; vcur_s[lane + 64] = v2;
-        uint16_t* Vw = kv.v + (size_t)page * kv.page_stride() + head_off;
-        Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
+        if (writer) {
+            uint16_t* Vw = kv.v + (size_t)page * kv.page_stride() + head_off;
+            Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
+        }
     }
     __syncthreads();
     const bool valid = lane < n, cur = lane == slot;
-    float a0 = 0.0f, a1 = 0.0f;
+    float a[HPW];
+#pragma unroll
+    for (int hh = 0; hh < HPW; hh++) a[hh] = 0.0f;
 #pragma unroll
     for (int d8 = 0; d8 < 16; d8++) {
         uint4 kk = kreg[d8];
@@ -821,18 +839,24 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
         const float kf[8] = { h2f(kk.x & 0xFFFFu), h2f(kk.x >> 16), h2f(kk.y & 0xFFFFu), h2f(kk.y >> 16),
                               h2f(kk.z & 0xFFFFu), h2f(kk.z >> 16), h2f(kk.w & 0xFFFFu), h2f(kk.w >> 16) };
 #pragma unroll
-        for (int e = 0; e < 8; e++) { a0 = q3_fmaf(q_s[0][8 * d8 + e], kf[e], a0); a1 = q3_fmaf(q_s[1][8 * d8 + e], kf[e], a1); }
-    }
-    const float s0 = valid ? a0 * scale : -INFINITY, s1 = valid ? a1 * scale : -INFINITY;
-    const float m0 = wave_max_bfly(s0), m1 = wave_max_bfly(s1);
-    const float p0 = valid ? q3_expf(s0 - m0) : 0.0f, p1 = valid ? q3_expf(s1 - m1) : 0.0f;
-    p_s[0][lane] = p0; p_s[1][lane] = p1;
-    const float l0 = wave_sum_bfly(p0), l1 = wave_sum_bfly(p1);
-    __syncthreads();
-    float y[2][8];
+        for (int e = 0; e < 8; e++)
 #pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
-        float s01[8], s23[8];
+            for (int hh = 0; hh < HPW; hh++) a[hh] = q3_fmaf(q_s[hh][8 * d8 + e], kf[e], a[hh]);
+    }
+    float L[HPW];
+#pragma unroll
+    for (int hh = 0; hh < HPW; hh++) {
+        const float sc = valid ? a[hh] * scale : -INFINITY;
+        const float m = wave_max_bfly(sc);
+        const float pv = valid ? q3_expf(sc - m) : 0.0f;
+        p_s[hh][lane] = pv;
+        L[hh] = wave_sum_bfly(pv);
+    }
+    __syncthreads();
+    const int dq = n_head * 128;
+#pragma unroll
+    for (int hh = 0; hh < HPW; hh++) {
+        float s01[8], s23[8], y[8];
 #pragma unroll
         for (int ww = 0; ww < 4; ww++) {
             float S[8];
@@ -843,9 +867,8 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
                 if (16 * u < n) {
                     const int jl = 16 * u + 4 * ww + jj;
                     const float pj = p_s[hh][jl];
-                    uint4 vv = make_uint4(0, 0, 0, 0);
-                    if (jl < n) vv = (jl == slot) ? *reinterpret_cast<const uint4*>(&vcur_s[dc * 8])
-                                                  : *reinterpret_cast<const uint4*>(Vb + jl * 128 + dc * 8);
+                    uint4 vv = vreg[ww][u]; // zero beyond the sequence
+                    if (jl == slot) vv = *reinterpret_cast<const uint4*>(&vcur_s[dc * 8]);
                     S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
                     S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
                     S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
@@ -859,21 +882,17 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
                 if (ww == 0) s01[i] = T; else if (ww == 1) s01[i] = s01[i] + T; else if (ww == 2) s23[i] = T; else s23[i] = s23[i] + T;
             }
         }
-        const float L = hh == 0 ? l0 : l1;
 #pragma unroll
-        for (int i = 0; i < 8; i++) y[hh][i] = (s01[i] + s23[i]) / L;
-    }
-    const int dq = n_head * 128;
-#pragma unroll
-    for (int hh = 0; hh < 2; hh++) {
+        for (int i = 0; i < 8; i++) y[i] = (s01[i] + s23[i]) / L[hh];
+        const int hq = h0 + hh;
         if (att && jj == 0) { // float-weight models consume the f32 rows
-            float* o = att + (size_t)tok * dq + (size_t)(2 * kvh + hh) * 128 + dc * 8;
-            *reinterpret_cast<float4*>(o) = make_float4(y[hh][0], y[hh][1], y[hh][2], y[hh][3]);
-            *reinterpret_cast<float4*>(o + 4) = make_float4(y[hh][4], y[hh][5], y[hh][6], y[hh][7]);
+            float* o = att + (size_t)tok * dq + (size_t)hq * 128 + dc * 8;
+            *reinterpret_cast<float4*>(o) = make_float4(y[0], y[1], y[2], y[3]);
+            *reinterpret_cast<float4*>(o + 4) = make_float4(y[4], y[5], y[6], y[7]);
         }
         float amax = 0.0f;
 #pragma unroll
-        for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
+        for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[i]));
         amax = fmaxf(amax, xor_lane<1>(amax));
         amax = fmaxf(amax, xor_lane<2>(amax));
         const float dd = amax / 127.0f;
@@ -882,19 +901,25 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
             uint32_t lo = 0, hi = 0;
 #pragma unroll
             for (int i = 0; i < 4; i++) {
-                lo |= (uint32_t)((int)q3_rintf(y[hh][i] * id) & 0xFF) << (8 * i);
-                hi |= (uint32_t)((int)q3_rintf(y[hh][i + 4] * id) & 0xFF) << (8 * i);
+                lo |= (uint32_t)((int)q3_rintf(y[i] * id) & 0xFF) << (8 * i);
+                hi |= (uint32_t)((int)q3_rintf(y[i + 4] * id) & 0xFF) << (8 * i);
             }
-            *reinterpret_cast<uint2*>(aq + (size_t)tok * dq + (size_t)(2 * kvh + hh) * 128 + dc * 8) = make_uint2(lo, hi);
-            if ((dc & 3) == 0) ad[(size_t)tok * (dq >> 5) + (2 * kvh + hh) * 4 + (dc >> 2)] = f2h(dd);
+            *reinterpret_cast<uint2*>(aq + (size_t)tok * dq + (size_t)hq * 128 + dc * 8) = make_uint2(lo, hi);
+            if ((dc & 3) == 0) ad[(size_t)tok * (dq >> 5) + hq * 4 + (dc >> 2)] = f2h(dd);
         }
     }
 }
 void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                             const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok, float* att) {
-    hipLaunchKernelGGL(k_attention_short, dim3(n_kv, ntok), dim3(64), 0, st, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, rope_cos,
-                       rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad, att);
+    // one q head per wave while that still leaves the chip under-filled (measured crossover: see DESIGN section 4)
+    static const int hpw1_max = [] { const char* e = std::getenv("Q3_SHORT_ATTN_HPW1_MAX"); return e ? atoi(e) : 128; }();
+    if (ntok <= hpw1_max)
+        hipLaunchKernelGGL(k_attention_short<1>, dim3(n_head, ntok), dim3(64), 0, st, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, rope_cos,
+                           rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad, att);
+    else
+        hipLaunchKernelGGL(k_attention_short<2>, dim3(n_kv, ntok), dim3(64), 0, st, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, rope_cos,
+                           rope_sin, n_ctx, mrope_sec, tm, kv, layer, aq, ad, att);
 }
 
 // ===================================================================================================
