@@ -83,9 +83,10 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
 
 __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                               float* __restrict__ out, int out_stride, int ntok);
-template <bool GU>
+template <bool GU, bool SM>
 __global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
     const int ntiles = (ntok + 31) / 32;
@@ -232,8 +233,12 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
-        hipLaunchKernelGGL((k_gemm_q8_mfma<false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                           out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+        if (q8_scale_mfma())
+            hipLaunchKernelGGL((k_gemm_q8_mfma<false, true>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+        else
+            hipLaunchKernelGGL((k_gemm_q8_mfma<false, false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
         return;
     }
     if (ntok > 8 && !lpr_hint) {
@@ -262,7 +267,8 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
     const int rgs = ff / 32, ntiles = (ntok + 31) / 32;
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-    hipLaunchKernelGGL((k_gemm_q8_mfma<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    if (q8_scale_mfma()) hipLaunchKernelGGL((k_gemm_q8_mfma<true, true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    else hipLaunchKernelGGL((k_gemm_q8_mfma<true, false>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
     return true;
 }
 
@@ -350,12 +356,17 @@ __global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrow
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
+typedef float f32x32q __attribute__((ext_vector_type(32)));
 // The workgroup keeps its weight tile (32 rows x one super-segment) in registers and loops over 32-token tiles
 // (tile = blockIdx.z, += gridDim.z), so weights are streamed once per launch when gridDim.z = 1.
 // GU = gate/up form for K <= 2048: pass 0 runs the 32 gate rows over the workgroup's tiles and parks the sums in LDS, pass 1
 // runs the 32 matching up rows and finishes with SwiGLU + int8 quantisation of the 32-row block (spec S8, S2); the f32
 // gate/up matrix never reaches memory.  A GU workgroup handles at most 4 token tiles (launcher picks gridDim.z accordingly).
-template <bool GU>
+// SM = the per-block scales d_x[token] * d_w[row] come from the f32 matrix pipe: both factors are f16 values, so the product is exact in
+// f32, and it is an outer product -- one v_mfma_f32_32x32x1_2b_f32 (K = 1: one exact product per output, C = 0) delivers the scale tiles of
+// two blocks in the C layout of the int8 MFMA.  That takes the 8 v_pk_mul_f32 + 4 ds_read_b128 per block and the LDS staging round (with
+// its barrier) off the VALU-bound chain; same bits (the product was exact before, too).
+template <bool GU, bool SM>
 __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                                                       int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
@@ -388,7 +399,7 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
 #pragma unroll 1
         for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z, lt++) {
             const int tok0 = tt * 32;
-            if (active) { // stage this wave's activation scales: token (lane & 31), blocks 4*(lane >> 5) .. +3
+            if (!SM && active) { // stage this wave's activation scales: token (lane & 31), blocks 4*(lane >> 5) .. +3
                 int t = tok0 + r;
                 if (t > ntok - 1) t = ntok - 1;
                 const uint2 v = *reinterpret_cast<const uint2*>(xd + (size_t)t * nb + seg * 8 + 4 * half);
@@ -396,11 +407,13 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                 sc_s[wave][th][4 * half + 0][tg] = h2f(v.x & 0xFFFFu); sc_s[wave][th][4 * half + 1][tg] = h2f(v.x >> 16);
                 sc_s[wave][th][4 * half + 2][tg] = h2f(v.y & 0xFFFFu); sc_s[wave][th][4 * half + 3][tg] = h2f(v.y >> 16);
             }
-            __syncthreads();
+            if (!SM) __syncthreads();
             if (active) {
                 int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
                 if (atok > ntok - 1) atok = ntok - 1;
                 const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+                uint4 dxa = make_uint4(0, 0, 0, 0);
+                if (SM) dxa = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8); // this token's 8 block scales
                 // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
                 // the scale chain runs on register pairs so it can issue as v_pk_mul_f32 / v_pk_fma_f32 (IEEE per component, same bits)
                 f32x2v acc2[8];
@@ -411,9 +424,16 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                     i32x4v av[4];
 #pragma unroll
                     for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + (4 * ih + i) * 32);
+                    f32x32q D;
 #pragma unroll
                     for (int i4 = 0; i4 < 4; i4++) {
                         const int i = 4 * ih + i4;
+                        if (SM && (i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
+#pragma unroll
+                            for (int g = 0; g < 32; g++) D[g] = 0.0f;
+                            const uint32_t ex = half ? half_of(dxa, i + 1) : half_of(dxa, i), ew = half ? half_of(dwv, i + 1) : half_of(dwv, i);
+                            D = __builtin_amdgcn_mfma_f32_32x32x1f32(h2f(ex), h2f(ew), D, 0, 0, 0);
+                        }
                         i32x16 c;
 #pragma unroll
                         for (int g = 0; g < 16; g++) c[g] = 0;
@@ -422,8 +442,14 @@ __global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nro
                         const f32x2v dw2 = f32x2v{dwf, dwf};
 #pragma unroll
                         for (int g4 = 0; g4 < 4; g4++) {
-                            const float4 sx = *reinterpret_cast<const float4*>(&sc_s[wave][half][i][4 * g4]);
-                            const f32x2v sc_a = dw2 * f32x2v{sx.x, sx.y}, sc_b = dw2 * f32x2v{sx.z, sx.w};
+                            f32x2v sc_a, sc_b;
+                            if (SM) {
+                                const int o = 16 * (i4 & 1) + 4 * g4;
+                                sc_a = f32x2v{D[o], D[o + 1]}; sc_b = f32x2v{D[o + 2], D[o + 3]};
+                            } else {
+                                const float4 sx = *reinterpret_cast<const float4*>(&sc_s[wave][half][i][4 * g4]);
+                                sc_a = dw2 * f32x2v{sx.x, sx.y}; sc_b = dw2 * f32x2v{sx.z, sx.w};
+                            }
                             const f32x2v ca = f32x2v{(float)c[4 * g4], (float)c[4 * g4 + 1]}, cb = f32x2v{(float)c[4 * g4 + 2], (float)c[4 * g4 + 3]};
                             acc2[2 * g4] = __builtin_elementwise_fma(ca, sc_a, acc2[2 * g4]);
                             acc2[2 * g4 + 1] = __builtin_elementwise_fma(cb, sc_b, acc2[2 * g4 + 1]);
