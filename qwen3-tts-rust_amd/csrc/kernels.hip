@@ -83,8 +83,13 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
 
 __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                               float* __restrict__ out, int out_stride, int ntok);
+// Register budget: 4 waves per SIMD (128 VGPRs), stated explicitly.  Measured on MI355X at 64 slots: with 2 waves per SIMD (256 VGPRs) the
+// kernel has room for a further exact trick -- start the int8 accumulator at the bit pattern of 1.5 * 2^23 so that float(dot) becomes one
+// v_pk_add_f32 per pair instead of two v_cvt_f32_i32 -- but the lost occupancy costs more than the 8 VALU instructions per block it saves
+// (AR step 5.64 vs 5.54 ms, prefill 52.7 vs 45.8 ms); squeezed into 128 VGPRs the constant tile spills (7.75 ms).
+#define Q3_GEMM_Q8_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <bool GU, bool SM>
-__global__ void k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
 static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
@@ -367,7 +372,7 @@ typedef float f32x32q __attribute__((ext_vector_type(32)));
 // two blocks in the C layout of the int8 MFMA.  That takes the 8 v_pk_mul_f32 + 4 ds_read_b128 per block and the LDS staging round (with
 // its barrier) off the VALU-bound chain; same bits (the product was exact before, too).
 template <bool GU, bool SM>
-__global__ void __launch_bounds__(512) k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
+__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                                                       int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ float red[8][32][33];
