@@ -424,15 +424,16 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
                 f32x2v acc2[8];
 #pragma unroll
                 for (int g = 0; g < 8; g++) acc2[g] = f32x2v{0.0f, 0.0f};
+                constexpr int AB = (SM && GU) ? 2 : 4; // activation blocks fetched at a time: keeps the kernel inside 128 VGPRs without spilling
 #pragma unroll
-                for (int ih = 0; ih < 2; ih++) { // activations of 4 blocks at a time: keeps the kernel under 128 VGPRs without spilling
-                    i32x4v av[4];
+                for (int ih = 0; ih < 8 / AB; ih++) {
+                    i32x4v av[AB];
 #pragma unroll
-                    for (int i = 0; i < 4; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + (4 * ih + i) * 32);
+                    for (int i = 0; i < AB; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + (AB * ih + i) * 32);
                     f32x32q D;
 #pragma unroll
-                    for (int i4 = 0; i4 < 4; i4++) {
-                        const int i = 4 * ih + i4;
+                    for (int i4 = 0; i4 < AB; i4++) {
+                        const int i = AB * ih + i4;
                         if (SM && (i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
 #pragma unroll
                             for (int g = 0; g < 32; g++) D[g] = 0.0f;
