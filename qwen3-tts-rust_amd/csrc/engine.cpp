@@ -138,7 +138,9 @@ Engine::Engine(const EngineParams& p) : p_(p) {
         // streams per decode pass, measured on MI355X: 64 slots 617 / 607 / 600 audio-s/s at 16 / 32 / 64, 256 slots 821 / 860 / 836
         static const int group_env = [] { const char* e = std::getenv("Q3_CODEC_GROUP"); return e ? atoi(e) : 0; }();
         const int group_cap = group_env > 0 ? group_env : (B >= 128 ? 32 : 16);
-        const int n_cs = B + std::min(B, 16), gmax = std::max(1, std::min(B, group_cap)), n_lanes = B > 1 ? 2 : 1;
+        const int n_cs = B + std::min(B, 16), gmax = std::max(1, std::min(B, group_cap));
+        static const int lanes_env = [] { const char* e = std::getenv("Q3_CODEC_LANES"); return e ? atoi(e) : 0; }();
+        const int n_lanes = B > 1 ? (lanes_env > 0 ? std::min(lanes_env, 8) : 2) : 1;
         codec_.reset(new CodecDecoder(p.model_dir + "/onnx/q3tts_codec.gguf", n_cs, 4, n_lanes, gmax));
         st2_.resize(n_lanes);
         for (auto& s2 : st2_) Q3_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
