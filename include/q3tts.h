@@ -183,6 +183,10 @@ int q3tts_tf_eval(q3tts_tf* t, const float* x, const int32_t* pos4, int32_t ntok
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,
                      const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);
+/* batched layer path (>= 16 tokens): fused gate/up GEMM on the matrix cores + SwiGLU + int8 quantisation; w = [2*ff][k] Q8_0 rows
+ * (gate rows first), k = 1024 or 2048; aq [ntok][ff], ad [ntok][ff/32] */
+int q3tts_op_gateup_q8(const void* w_q8_0, int32_t ff, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok, int8_t* aq,
+                       uint16_t* ad);
 /* float-weight matmul (spec S3 float form; ggml types 0 = f32, 1 = f16, 30 = bf16): ntok >= 12 runs the matrix-core kernel,
  * fewer tokens the one-wave-per-row GEMV; row0 selects a row range like the head of the code predictor does */
 int q3tts_op_matmul_float(const void* w /* [n][k] */, int32_t type, int32_t n, int32_t k, int32_t row0, int32_t nrows,

@@ -11,3 +11,4 @@ int q3o_spec_mrope_stream(int i, const int32_t* sec) { return q3_mrope_stream(i,
 void q3o_spec_f16_to_f32_n(const uint16_t* h, float* f, int64_t n) { for (int64_t i = 0; i < n; i++) f[i] = q3_f16_to_f32(h[i]); }
 void q3o_spec_f32_to_f16_n(const float* f, uint16_t* h, int64_t n) { for (int64_t i = 0; i < n; i++) h[i] = q3_f32_to_f16(f[i]); }
 void q3o_spec_expf_n(const float* x, float* y, int64_t n) { for (int64_t i = 0; i < n; i++) y[i] = q3_expf(x[i]); }
+void q3o_spec_swiglu_vec(const float* g, const float* u, int64_t n, float* out) { for (int64_t i = 0; i < n; i++) out[i] = q3_swiglu(g[i], u[i]); }

@@ -6,8 +6,8 @@
 
 using namespace q3;
 
-struct q3tts_engine { std::unique_ptr<Engine> e; };
 struct q3tts_assets { std::unique_ptr<HostAssets> owned; const HostAssets* a = nullptr; };
+struct q3tts_engine { std::unique_ptr<Engine> e; q3tts_assets assets_view; }; // the view lives exactly as long as the engine
 struct q3tts_sampler { Sampler s; };
 struct q3tts_chunker { std::unique_ptr<Chunker> c; };
 struct q3tts_decoder { std::unique_ptr<CodecDecoder> d; hipStream_t st = nullptr; float* pinned = nullptr; size_t pinned_cap = 0; };
@@ -43,6 +43,7 @@ int q3tts_engine_create(const q3tts_engine_params* p, q3tts_engine** out) {
     ep.max_steps = p->max_steps; ep.load_codec = p->load_codec != 0; ep.use_graph = p->use_graph != 0;
     auto* h = new q3tts_engine();
     try { h->e.reset(new Engine(ep)); } catch (...) { delete h; throw; }
+    h->assets_view.a = &h->e->assets();
     *out = h;
     return Q3TTS_OK;
     Q3_API_END(Q3TTS_ERR)
@@ -185,12 +186,7 @@ int q3tts_assets_open(const char* path, q3tts_assets** out) {
     Q3_API_END(Q3TTS_ERR)
 }
 void q3tts_assets_close(q3tts_assets* a) { delete a; }
-const q3tts_assets* q3tts_engine_assets(q3tts_engine* e) {
-    static thread_local q3tts_assets view;
-    if (!e) return nullptr;
-    view.a = &e->e->assets();
-    return &view;
-}
+const q3tts_assets* q3tts_engine_assets(q3tts_engine* e) { return e ? &e->assets_view : nullptr; }
 int q3tts_assets_codec_embedding(const q3tts_assets* a, int32_t q, int32_t code, float* out) { Q3_API_BEGIN a->a->codec_embedding(q, code, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 int q3tts_assets_text_embedding(const q3tts_assets* a, int64_t tok, float* out) { Q3_API_BEGIN a->a->text_embedding(tok, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 int q3tts_assets_tts_pad(const q3tts_assets* a, float* out) { Q3_API_BEGIN std::copy(a->a->tts_pad(), a->a->tts_pad() + 2048, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }

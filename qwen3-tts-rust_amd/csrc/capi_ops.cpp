@@ -36,6 +36,24 @@ int q3tts_op_gemv_q8(const void* w, int32_t n, int32_t k, const int8_t* xq, cons
     Q3_API_END(Q3TTS_ERR)
 }
 
+/* fused gate/up GEMM + SwiGLU + int8 quantisation of the batched (>= 16 token) layer path; w = [2*ff][k] Q8_0 rows, gate rows first */
+int q3tts_op_gateup_q8(const void* w, int32_t ff, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok, int8_t* aq, uint16_t* ad) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(w && xq && xd && aq && ad && ff > 0 && ff % 32 == 0 && k % 256 == 0 && ntok >= 1, "bad gate/up shape");
+    DevBuf<uint8_t> storage;
+    Q8Mat m = q8mat_from_host(w, 2 * ff, k, storage);
+    DevBuf<int8_t> dxq((size_t)ntok * k); dxq.upload(xq, dxq.n);
+    DevBuf<uint16_t> dxd((size_t)ntok * (k / 32)); dxd.upload(xd, dxd.n);
+    DevBuf<int8_t> daq((size_t)ntok * ff); DevBuf<uint16_t> dad((size_t)ntok * (ff / 32));
+    if (!launch_gateup_mfma(0, m, ff, dxq.p, dxd.p, daq.p, dad.p, ntok)) throw Error("shape not served by the fused gate/up matrix-core kernel");
+    Q3_LAUNCH_CHECK();
+    Q3_HIP(hipDeviceSynchronize());
+    daq.download(aq, daq.n); dad.download(ad, dad.n);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
 int q3tts_op_matmul_float(const void* w, int32_t type, int32_t n, int32_t k, int32_t row0, int32_t nrows, const float* x, int32_t ntok, float* y) {
     Q3_API_BEGIN
     require_gpu();

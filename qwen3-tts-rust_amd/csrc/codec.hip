@@ -902,6 +902,7 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
     hipLaunchKernelGGL(k_conv_out_wave, dim3((G * T + 3) / 4), dim3(256), 0, st, m.work(m.out_ext), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T,
                        m.base_map(m.out_ext, T));
     m.move_hist(st, G, meta, true);
+    Q3_LAUNCH_CHECK();
     for (int g = 0; g < G; g++) Q3_HIP(hipMemcpyAsync(pcm[g], m.S->pcm.p + (size_t)g * T, (size_t)T * 4, hipMemcpyDeviceToHost, st));
     return T;
 }

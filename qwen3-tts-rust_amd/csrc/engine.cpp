@@ -264,6 +264,7 @@ void Engine::record_frame(FrameGraph& fg, bool sampled) {
     }
     AdvanceKeysArgs a{B, d_finished_.p, d_nframes_.p, d_maxframes_.p, d_keys_.p, d_next_key0_.p, d_hist_.p, hist_stride_, d_tslot_.p, d_tpos_.p};
     launch_advance_keys(st_, a);
+    Q3_LAUNCH_CHECK();
 }
 
 Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {

@@ -16,12 +16,12 @@ namespace {
 struct Cursor {
     const uint8_t* p; const uint8_t* end;
     template <typename T> T get() {
-        if (p + sizeof(T) > end) throw Error("truncated GGUF header");
+        if (sizeof(T) > (size_t)(end - p)) throw Error("truncated GGUF header");
         T v; std::memcpy(&v, p, sizeof(T)); p += sizeof(T); return v;
     }
     std::string str() {
         uint64_t n = get<uint64_t>();
-        if (p + n > end) throw Error("truncated GGUF string");
+        if (n > (uint64_t)(end - p)) throw Error("truncated GGUF string"); // (compare sizes: p + n could wrap)
         std::string s((const char*)p, (size_t)n); p += n; return s;
     }
 };
@@ -50,6 +50,8 @@ int64_t GgufValue::as_int(int64_t def) const { return (type >= 0 && type != 8 &&
 double GgufValue::as_float(double def) const { return (type >= 0 && type != 8 && type != 9) ? f : def; }
 
 size_t Gguf::row_bytes(int type, int64_t k) {
+    const int64_t blk = (type == Q3_T_Q8_0) ? 32 : (type == Q3_T_Q5_K || type == Q3_T_Q6_K) ? 256 : 1;
+    if (k <= 0 || k % blk != 0) return 0; // a partial block would silently truncate the row
     switch (type) {
         case Q3_T_F32: return (size_t)k * 4;
         case Q3_T_F16: case Q3_T_BF16: return (size_t)k * 2;
@@ -63,7 +65,8 @@ size_t Gguf::row_bytes(int type, int64_t k) {
 Gguf::Gguf(const std::string& path) {
     fd_ = ::open(path.c_str(), O_RDONLY);
     if (fd_ < 0) throw Error("cannot open " + path);
-    struct stat st; fstat(fd_, &st);
+    struct stat st;
+    if (fstat(fd_, &st) != 0 || st.st_size <= 0) { ::close(fd_); fd_ = -1; throw Error("cannot stat " + path); }
     size_ = (size_t)st.st_size;
     void* m = mmap(nullptr, size_, PROT_READ, MAP_PRIVATE, fd_, 0);
     if (m == MAP_FAILED) { ::close(fd_); fd_ = -1; throw Error("mmap failed: " + path); }
@@ -85,7 +88,10 @@ Gguf::Gguf(const std::string& path) {
                 if (v.arr_type == 8) { for (uint64_t j = 0; j < v.arr_n; j++) (void)c.str(); }
                 else { if (scalar_size(v.arr_type) < 0) throw Error("Unknown GGUF array type"); for (uint64_t j = 0; j < v.arr_n; j++) read_scalar(c, v.arr_type, v, true); }
             } else read_scalar(c, v.type, v, false);
-            if (key == "general.alignment" && v.type == 4) alignment = v.u;
+            if (key == "general.alignment" && v.type == 4) {
+                alignment = v.u;
+                if (alignment == 0 || (alignment & (alignment - 1)) != 0 || alignment > (1u << 20)) throw Error("general.alignment must be a power of two");
+            }
             kvs[key] = std::move(v);
         }
         tensors.resize((size_t)nt);
@@ -93,7 +99,11 @@ Gguf::Gguf(const std::string& path) {
             t.name = c.str();
             t.n_dims = (int)c.get<uint32_t>();
             if (t.n_dims > 4) throw Error("tensor " + t.name + ": too many dims");
-            for (int d = 0; d < t.n_dims; d++) t.ne[d] = (int64_t)c.get<uint64_t>();
+            for (int d = 0; d < t.n_dims; d++) {
+                const uint64_t ne = c.get<uint64_t>();
+                if (ne == 0 || ne > ((uint64_t)1 << 40)) throw Error("tensor " + t.name + ": implausible dimension");
+                t.ne[d] = (int64_t)ne;
+            }
             t.type = (int)c.get<uint32_t>();
             t.offset = c.get<uint64_t>();
         }
@@ -102,9 +112,13 @@ Gguf::Gguf(const std::string& path) {
         for (size_t i = 0; i < tensors.size(); i++) {
             auto& t = tensors[i];
             size_t rb = row_bytes(t.type, t.ne[0]);
-            if (!rb) throw Error("Unsupported tensor type: " + std::to_string(t.type) + " (" + t.name + ")");
-            t.nbytes = rb * (size_t)t.rows();
-            if (data_start + t.offset + t.nbytes > size_) throw Error("tensor " + t.name + " out of file");
+            if (!rb) throw Error("Unsupported tensor type or row length: type " + std::to_string(t.type) + ", ne0 " + std::to_string(t.ne[0]) + " (" + t.name + ")");
+            size_t rows = 1;
+            for (int d = 1; d < 4; d++) if (__builtin_mul_overflow(rows, (size_t)t.ne[d], &rows)) throw Error("tensor " + t.name + ": size overflow");
+            size_t end_off = 0;
+            if (__builtin_mul_overflow(rb, rows, &t.nbytes) || __builtin_add_overflow((size_t)t.offset, t.nbytes, &end_off) ||
+                __builtin_add_overflow(end_off, data_start, &end_off) || end_off > size_ || data_start > size_)
+                throw Error("tensor " + t.name + " out of file");
             t.data = map_ + data_start + t.offset;
             index_[t.name] = i;
         }

@@ -248,9 +248,11 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     }
     if (ntok > 8 && !lpr_hint) {
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
-        static bool attr_set = false;
         const size_t lds = 16 * 2048 + 16 * 128 + 8 * 16 * 64 * 4; // 66 KiB: activations of 16 tokens + segment sums
-        if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+        static bool attr_set[64] = {}; // the opt-in is per device
+        int dev = 0;
+        Q3_HIP(hipGetDevice(&dev));
+        if (dev >= 0 && dev < 64 && !attr_set[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set[dev] = true; }
         hipLaunchKernelGGL(k_gemm_q8_tok, dim3((nrows + 63) / 64, nsseg, (ntok + 15) / 16), dim3(64 * nw), lds, st, w, row0, nrows, xq, xd, out,
                            out_stride, ntok);
         return;
@@ -1287,11 +1289,10 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
     static const int min_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_MIN"); return e ? atoi(e) : 2; }();
     if (!w.wt || min_tok <= 0 || ntok < min_tok || row0 % 64 != 0 || (w.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
     constexpr size_t lds = (size_t)Q3_SSEG_SEGS * 64 * FM_PAD * sizeof(float);
-    static const bool attr_set = [] {
-        Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<TYPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        return true;
-    }();
-    (void)attr_set;
+    static bool attr_set[64] = {}; // the opt-in is per device
+    int dev = 0;
+    Q3_HIP(hipGetDevice(&dev));
+    if (dev >= 0 && dev < 64 && !attr_set[dev]) { Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<TYPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[dev] = true; }
     static const int wide_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WIDE"); return e ? atoi(e) : 96; }();
     if (ntok < wide_tok) { // few tokens: 16 x 16 tiles, 16x more workgroups
         dim3 grid16(xcd_grid((nrows + 15) / 16, (ntok + 15) / 16));

@@ -977,16 +977,19 @@ __global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x,
 }
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
                         float* out, int out_stride, int ntok) {
-    static bool attr_set = false, attr_mt = false;
+    static bool attr_set[64] = {}, attr_mt[64] = {}; // the dynamic-LDS opt-in is per device
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    dev = dev < 0 || dev > 63 ? 0 : dev;
     static const int mt_min = [] { const char* e = std::getenv("Q3_PROJECT_MT_MIN"); return e ? atoi(e) : 3; }(); // experiment knob
     if (ntok >= mt_min) {
-        if (!attr_mt) { (void)hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_mt = true; }
+        if (!attr_mt[dev]) { (void)hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_mt[dev] = true; }
         hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), (size_t)n_in * 16 * sizeof(float), st, x, x_stride, Wblk, b,
                            n_in, n_out, out, out_stride, ntok);
         return;
     }
     const size_t lds = (size_t)n_in * 17 * sizeof(float);
-    if (!attr_set) { (void)hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set = true; }
+    if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[dev] = true; }
     hipLaunchKernelGGL(k_project_blk, dim3(n_out / 16, ntok), dim3(256), lds, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride);
 }
 

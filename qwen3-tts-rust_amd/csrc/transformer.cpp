@@ -315,6 +315,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         }
         // final norm is the prologue of head(); hidden_out is produced there too
         if (hidden_out) head(st, 0, ntok, 0, 0, nullptr, 0, nullptr, -1, hidden_out);
+        Q3_LAUNCH_CHECK();
         return;
     }
     const bool wgnorm = ntok > 8; // batched steps: workgroup-per-token norm kernel (same arithmetic, one global round trip)
@@ -368,6 +369,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
     f.h_in = h_.p; f.h_stride = d; f.parts = parts_d_.p; f.nparts = nparts_d_; f.parts_stride = d; f.h_out = nullptr;
     f.g = output_norm_; f.eps = hp_.eps; f.d = d; f.xq = xq_.p; f.xd = xd_.p; f.xn_out = hidden_out ? hidden_out : hid_.p;
     norm(f);
+    Q3_LAUNCH_CHECK();
 }
 
 void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
@@ -413,10 +415,16 @@ void Transformer::forward_float(hipStream_t st, const Input& in, int ntok, const
     }
     norm(h_.p, d, nullptr, 0, parts_d_.p, output_norm_, hidden_out ? hidden_out : hid_.p);
     if (hidden_out) launch_copy_f32(st, hidden_out, hid_.p, (size_t)ntok * d);
+    Q3_LAUNCH_CHECK();
 }
 
 void Transformer::head(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
                        const ArgmaxEpi* am, int nrows_valid, float* hidden_out) {
+    head_impl(st, tok0, tok_count, row0, nrows, logits, logits_stride, am, nrows_valid, hidden_out);
+    Q3_LAUNCH_CHECK();
+}
+void Transformer::head_impl(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride,
+                            const ArgmaxEpi* am, int nrows_valid, float* hidden_out) {
     const int d = hp_.n_embd;
     Q3_CHECK(row0 % 32 == 0 && (float_mode_ || row0 + nrows <= output_.Npad), "head row range");
     if (last_fused_) {

@@ -56,6 +56,8 @@ public:
     const Q8Mat& mat_out() const { return output_; }
 
 private:
+    void head_impl(hipStream_t st, int tok0, int tok_count, int row0, int nrows, float* logits, int logits_stride, const ArgmaxEpi* am,
+                   int nrows_valid, float* hidden_out);
     struct Layer { Q8Mat wqkv, wo, wgu, wdown; FMat fqkv, fo, fgu, fdown; float *attn_norm, *q_norm, *k_norm, *ffn_norm; };
     FMat make_fmat(const Gguf& g, const std::vector<std::string>& names, int K_expect);
     void forward_float(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out);

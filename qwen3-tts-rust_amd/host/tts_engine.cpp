@@ -19,12 +19,39 @@ struct JP {
     [[noreturn]] void fail(const char* m) { throw std::runtime_error(std::string("json: ") + m + " at " + std::to_string(i)); }
     char peek() { ws(); if (i >= s.size()) fail("eof"); return s[i]; }
     void expect(char c) { if (peek() != c) fail("unexpected character"); i++; }
+    uint32_t hex4() {
+        if (i + 4 > s.size()) fail("truncated \\u escape");
+        uint32_t v = 0;
+        for (int k = 0; k < 4; k++) { const char c = s[i++]; v = v * 16 + (c >= '0' && c <= '9' ? c - '0' : c >= 'a' && c <= 'f' ? c - 'a' + 10 : c >= 'A' && c <= 'F' ? c - 'A' + 10 : (fail("bad hex digit"), 0)); }
+        return v;
+    }
+    static void utf8(std::string& o, uint32_t cp) {
+        if (cp < 0x80) o += (char)cp;
+        else if (cp < 0x800) { o += (char)(0xC0 | (cp >> 6)); o += (char)(0x80 | (cp & 0x3F)); }
+        else if (cp < 0x10000) { o += (char)(0xE0 | (cp >> 12)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+        else { o += (char)(0xF0 | (cp >> 18)); o += (char)(0x80 | ((cp >> 12) & 0x3F)); o += (char)(0x80 | ((cp >> 6) & 0x3F)); o += (char)(0x80 | (cp & 0x3F)); }
+    }
     std::string str() {
         expect('"');
         std::string o;
         while (i < s.size() && s[i] != '"') {
-            if (s[i] == '\\' && i + 1 < s.size()) { char c = s[++i]; o += c == 'n' ? '\n' : c == 't' ? '\t' : c; i++; }
-            else o += s[i++];
+            if (s[i] == '\\' && i + 1 < s.size()) {
+                const char c = s[++i]; i++;
+                switch (c) { // the full JSON escape set (serde_json and Python's json emit \uXXXX / \r / \b / \f for ref_text)
+                    case 'n': o += '\n'; break; case 't': o += '\t'; break; case 'r': o += '\r'; break;
+                    case 'b': o += '\b'; break; case 'f': o += '\f'; break;
+                    case 'u': {
+                        uint32_t cp = hex4();
+                        if (cp >= 0xD800 && cp <= 0xDBFF) { // surrogate pair
+                            if (i + 1 < s.size() && s[i] == '\\' && s[i + 1] == 'u') { i += 2; const uint32_t lo = hex4(); if (lo < 0xDC00 || lo > 0xDFFF) fail("bad low surrogate"); cp = 0x10000 + ((cp - 0xD800) << 10) + (lo - 0xDC00); }
+                            else fail("lone high surrogate");
+                        } else if (cp >= 0xDC00 && cp <= 0xDFFF) fail("lone low surrogate");
+                        utf8(o, cp);
+                        break;
+                    }
+                    default: o += c; // \" \\ \/
+                }
+            } else o += s[i++];
         }
         if (i >= s.size()) fail("unterminated string");
         i++;
@@ -49,7 +76,16 @@ struct JP {
     }
     std::optional<std::string> optstr() { if (peek() == 'n') { i += 4; return std::nullopt; } return str(); }
 };
-std::string esc(const std::string& s) { std::string o; for (char c : s) { if (c == '"' || c == '\\') o += '\\'; o += c; } return o; }
+std::string esc(const std::string& s) { // control characters must be escaped (RFC 8259); UTF-8 bytes pass through
+    std::string o;
+    for (unsigned char c : s) {
+        if (c == '"' || c == '\\') { o += '\\'; o += (char)c; }
+        else if (c == '\n') o += "\\n"; else if (c == '\t') o += "\\t"; else if (c == '\r') o += "\\r"; else if (c == '\b') o += "\\b"; else if (c == '\f') o += "\\f";
+        else if (c < 0x20) { char b[8]; snprintf(b, sizeof b, "\\u%04x", c); o += b; }
+        else o += (char)c;
+    }
+    return o;
+}
 }
 
 VoiceFile VoiceFile::load(const std::string& path) {

@@ -61,7 +61,7 @@ SYMBOLS = [
     "q3tts_prompt_build_clone", "q3tts_sampler_new", "q3tts_sampler_free", "q3tts_sampler_sample", "q3tts_chunker_new",
     "q3tts_chunker_free", "q3tts_chunker_push", "q3tts_decoder_create", "q3tts_decoder_destroy", "q3tts_decoder_samples_per_frame",
     "q3tts_decoder_reset", "q3tts_decoder_decode", "q3tts_mel_frames", "q3tts_mel", "q3tts_tf_open", "q3tts_tf_close",
-    "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_matmul_float", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
+    "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_gateup_q8", "q3tts_op_matmul_float", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
     "q3tts_op_argmax", "q3tts_op_project", "q3tts_op_sample", "q3tts_submit", "q3tts_poll", "q3tts_fetch", "q3tts_wait",
     "q3tts_release", "q3tts_decoder_create_ex", "q3tts_decoder_decode_group", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
 ]
@@ -129,6 +129,7 @@ def lib():
         L.q3tts_tf_clear.argtypes = [C.c_void_p]
         L.q3tts_tf_eval.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32]
         L.q3tts_op_gemv_q8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+        L.q3tts_op_gateup_q8.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
         L.q3tts_op_matmul_float.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p]
         L.q3tts_op_rmsnorm_quant.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_float, C.c_void_p, C.c_void_p, C.c_void_p]
         L.q3tts_op_swiglu_quant.argtypes = [C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p]
@@ -460,6 +461,17 @@ def op_gemv_q8(w_raw, n, k, xq, xd, lpr=0):
     y = np.zeros((xq.shape[0], n), np.float32)
     _chk(lib().q3tts_op_gemv_q8(_p(w_raw), n, k, _p(xq), _p(xd), xq.shape[0], _p(y), lpr))
     return y
+
+
+def op_gateup_q8(w_raw, ff, k, xq, xd):
+    """fused gate/up + SwiGLU + quant of the batched layer path: w_raw = Q8_0 rows [2*ff][k/32][34] (gate first)"""
+    xq = np.ascontiguousarray(xq, np.int8).reshape(-1, k)
+    xd = np.ascontiguousarray(xd, np.uint16).reshape(-1, k // 32)
+    w_raw = np.ascontiguousarray(w_raw, np.uint8)
+    aq = np.zeros((xq.shape[0], ff), np.int8)
+    ad = np.zeros((xq.shape[0], ff // 32), np.uint16)
+    _chk(lib().q3tts_op_gateup_q8(_p(w_raw), ff, k, _p(xq), _p(xd), xq.shape[0], _p(aq), _p(ad)))
+    return aq, ad
 
 
 def op_matmul_float(w_raw, ggml_type, n, k, x, row0=0, nrows=None):

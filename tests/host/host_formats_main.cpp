@@ -36,6 +36,12 @@ int main(int argc, char** argv) {
         v.save(dir + "/voice_out.json");
         VoiceFile w = VoiceFile::load(dir + "/voice_out.json");
         if (w.speaker_embedding != v.speaker_embedding || w.audio_codes != v.audio_codes || w.ref_text != v.ref_text) throw std::runtime_error("VoiceFile round trip");
+        // written by Python's json with ensure_ascii (\uXXXX incl. a surrogate pair) and control characters: the full escape set
+        VoiceFile u = VoiceFile::load(dir + "/voice_uni.json");
+        if (u.ref_text != "\xe4\xbd\xa0\xe5\xa5\xbd \xf0\x9f\x8e\xa4\nline2\ttab\r\b\f\"q\"\\" || !u.name || *u.name != "\xc3\xa9") throw std::runtime_error("VoiceFile unicode escapes");
+        u.save(dir + "/voice_uni_out.json");                                // Python parses this file and compares
+        VoiceFile u2 = VoiceFile::load(dir + "/voice_uni_out.json");
+        if (u2.ref_text != u.ref_text || *u2.name != *u.name) throw std::runtime_error("VoiceFile escape round trip");
         printf("OK\n");
     } catch (const std::exception& e) { fprintf(stderr, "FAILED: %s\n", e.what()); return 1; }
     return 0;

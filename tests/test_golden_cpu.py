@@ -43,3 +43,35 @@ def test_q5_k_m_and_bf16_oracle_paths_run(tiny_model, oracle, vivian):
         runs[sub], _ = eng.generate(prompt, max_steps=4, temperature=0.0, seed=42, mask_eos=True)
         eng.close()
         assert runs[sub].shape == (4, 16) and runs[sub].min() >= 0 and runs[sub][:, 1:].max() < 2048 and runs[sub][:, 0].max() < 2160
+
+
+TF_GGUF = os.path.join(ROOT, "tests", "golden", "qwen3_tf_f16.gguf")
+TF_EXP = os.path.join(ROOT, "tests", "golden", "qwen3_tf_expected.npz")
+TF_TOL = 2e-3   # f32 torch (f32 softmax/KV) vs spec arithmetic with an f16 KV cache; relative to max(1, |ref|_inf)
+
+
+def test_oracle_vs_transformers_fixture(oracle):
+    """The committed fixture was computed by `transformers` Qwen3Model (tests/golden/make_transformers_fixture.py), not by oracle/:
+    it pins the oracle's transformer math to an independent implementation; the same fixture pins the HIP path on the GPU box."""
+    g = np.load(TF_EXP)
+    D, L, H, HKV, FF, V, N = [int(v) for v in g["meta"]]
+    om = oracle.Model(TF_GGUF, 64)
+    for i in range(N):
+        h, lg = om.eval(g["x"][i], [i, i, i, 0], D, 0, V)
+        assert np.abs(h - g["hidden"][i]).max() < TF_TOL * max(1.0, np.abs(g["hidden"][i]).max()), i
+        assert np.abs(lg - g["logits"][i]).max() < TF_TOL * max(1.0, np.abs(g["logits"][i]).max()), i
+    om.close()
+
+
+def test_oracle_q8_path_vs_transformers_fixture(oracle):
+    """same numbers, the model quantised to Q8_0: the oracle's int8 path (block quantisation of activations, integer dots, scale chain)
+    stays within the 8-bit quantisation noise of the float32 transformers result (measured 3e-2; a wrong scale, block order or sign
+    shows up as O(1))."""
+    g = np.load(TF_EXP)
+    D, L, H, HKV, FF, V, N = [int(v) for v in g["meta"]]
+    om = oracle.Model(os.path.join(ROOT, "tests", "golden", "qwen3_tf_q8_0.gguf"), 64)
+    for i in range(N):
+        h, lg = om.eval(g["x"][i], [i, i, i, 0], D, 0, V)
+        assert np.abs(h - g["hidden"][i]).max() < 6e-2 * max(1.0, np.abs(g["hidden"][i]).max()), i
+        assert np.abs(lg - g["logits"][i]).max() < 6e-2 * max(1.0, np.abs(g["logits"][i]).max()), i
+    om.close()

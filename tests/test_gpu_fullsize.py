@@ -40,3 +40,53 @@ def test_fullsize_parity_and_properties(gpu, oracle, full_model, vivian):
     ref = oc2.decode(np.clip(r["codes"][:5], 0, 2047)).copy(); oc2.close()
     assert np.sqrt(np.mean((ref - r["pcm"][: ref.size]) ** 2)) < 1e-4
     ge.close()
+
+
+def test_fullsize_batched_c3_shapes_vs_oracle_singles(gpu, oracle, full_model, vivian):
+    """BASELINE config C3 at its real dimensions: 32 slots of the full Q3TTS-1.7B-synth model step together, so every batched
+    (>= 16 token) kernel form runs at K = 2048 / 6144 (talker) and K = 1024 / 3072 (predictor, incl. the fused gate/up matrix-core
+    kernel that the tiny model's K = 256 cannot reach), the multi-sequence prefill packs 32 prompts, and continuous batching retires
+    slots at different frames.  Three of the 32 requests are compared with the oracle run ALONE on the host: tokens bit-exact."""
+    ge = gpu.Engine(full_model, "q8_0", max_batch=32, max_steps=16, load_codec=False)
+    prompts = []
+    for i in range(32):
+        rng = np.random.default_rng(500 + i)
+        prompts.append(ge.assets.build_core(rng.integers(0, 4000, 3 + (i % 3)).astype(np.int32), lang_id=2055, spk_emb=vivian))
+    assert prompts[0].shape == (14, 2048)
+    ms = [3 + (i % 4) for i in range(32)]            # ragged lengths: slots retire at different frames
+    res = ge.generate_batch(prompts, max_steps=ms, mask_eos=True)
+    st = ge.stats()
+    assert st["slot_frames"] / max(st["graph_frames"], 1) >= 16, "the batched (>= 16 token) graph widths were not exercised"
+    for r, m in zip(res, ms):
+        assert r["codes"].shape == (m, 16) and r["codes"].min() >= 0 and r["codes"][:, 0].max() < 2160 and r["codes"][:, 1:].max() < 2048
+    oe = oracle.Engine(os.path.join(full_model, "gguf_q8_0"), None, 8)
+    for i in (0, 13, 31):
+        oc, _ = oe.generate(prompts[i], max_steps=3, mask_eos=True)
+        assert np.array_equal(oc, res[i]["codes"][:3]), i
+    oe.close()
+    # batch invariance at full size: the same request alone gives the same tokens
+    solo = ge.generate_batch([prompts[7]], max_steps=ms[7], mask_eos=True)[0]
+    assert np.array_equal(solo["codes"], res[7]["codes"])
+    ge.close()
+
+
+def test_fullsize_codec_group16_vs_oracle(gpu, oracle, full_model):
+    """q3tts_decoder_decode_group at full codec size: 16 streams with different histories, two 4-frame chunks each in one pass per
+    chunk (the batched extended-buffer GEMMs at G*T rows, split-f16 kernels above 32 rows) vs the oracle stream by stream (1e-4 RMS)."""
+    path = os.path.join(full_model, "onnx", "q3tts_codec.gguf")
+    gd = gpu.Decoder(path, n_streams=17, max_frames=4, max_group=16)
+    rng = np.random.default_rng(21)
+    codes = rng.integers(0, 2048, (16, 8, 16))
+    streams = [(5 * i + 3) % 17 for i in range(16)]
+    assert len(set(streams)) == 16
+    for s in streams:
+        gd.reset(s)
+    got = np.concatenate([gd.decode_group(streams, codes[:, o:o + 4]) for o in (0, 4)], axis=1)
+    assert np.isfinite(got).all()
+    oc = oracle.Codec(path)
+    for i in (0, 6, 15):                              # ~1.5 s of host time per stream
+        oc.reset()
+        ref = oc.decode(codes[i]).copy()
+        assert ref.shape == got[i].shape
+        assert np.sqrt(np.mean((ref - got[i]) ** 2)) < 1e-4, i
+    oc.close(); gd.close()

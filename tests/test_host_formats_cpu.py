@@ -33,6 +33,8 @@ def test_cache_wav_voicefile_formats(tmp_path):
     open(os.path.join(d, "py.wav"), "wb").write(b"RIFF" + struct.pack("<I", len(body)) + body)
     json.dump({"ref_text": "hi", "audio_codes": [5, 6], "spk_emb": [0.25, -1.0, 2.0, 0.0], "name": "n", "extra_key": {"ignored": True}},
               open(os.path.join(d, "voice.json"), "w"))
+    uni = "\u4f60\u597d \U0001F3A4\nline2\ttab\r\b\f\"q\"\\"
+    json.dump({"ref_text": uni, "audio_codes": [], "speaker_embedding": [1.0], "name": "\u00e9"}, open(os.path.join(d, "voice_uni.json"), "w"))  # ensure_ascii
     exe = os.path.join(d, "host_formats_main")
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host", "host_formats_main.cpp"),
                            "-L" + PKG, "-lq3tts_host", "-lq3tts", "-Wl,-rpath," + PKG, "-Wl,-rpath,/opt/rocm/lib"])
@@ -44,3 +46,5 @@ def test_cache_wav_voicefile_formats(tmp_path):
     assert struct.unpack("<6h", raw[44:56]) == (0, 32767, -32767, 16383, 32767, -32768)    # audio.rs:36: (s*32767).clamp(-32768,32767) as i16
     out = json.load(open(os.path.join(d, "voice_out.json")))
     assert out["ref_text"] == "hi" and out["audio_codes"] == [5, 6] and out["speaker_embedding"] == [0.25, -1.0, 2.0, 0.0]
+    out2 = json.load(open(os.path.join(d, "voice_uni_out.json"), encoding="utf-8"))
+    assert out2["ref_text"] == uni and out2["name"] == "\u00e9"                        # control characters escaped, UTF-8 passed through
