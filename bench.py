@@ -1,13 +1,21 @@
 #!/usr/bin/env python3
 """bench.py -- headline benchmark of the MI355X-native Qwen3-TTS hot path (contract in the task prompt, part 4).
 
-Workload (config C2 of BASELINE.json / SURVEY.md 8d): single utterance per GPU, "Q3TTS-1.7B-synth" Q8_0 weights
-(seeded random, written on the box by tools/q3synth), speaker = vivian, preset prompt with 32 synthetic text ids
-(43 prompt rows), greedy (temperature 0, seed 42), EOS masked so every run emits exactly 4*K frames.
-One "step" = one 4-frame streaming step (4 x [talker + 15-pass predictor] hipGraph replays + one codec chunk).
-The timed region is one whole utterance of K steps: prompt upload + prefill + K steps, inputs resident in HBM
-except the 352 KB prompt (the span the reference's CLI times, src/bin/qwen3_tts.rs:144-153).
-value = audio seconds generated per wall second, summed over ranks (weak scaling: one utterance per GPU).
+Default workload = BASELINE.json configs[2] ("C3", the largest single-GPU configuration): 64 concurrent utterances through
+64 sequence slots per GPU, "Q3TTS-1.7B-synth" Q8_0 weights (seeded random, written on the box by tools/q3synth), speaker = vivian,
+preset prompts with 16/32/64 synthetic text ids round-robin (27/43/75 prompt rows), greedy (temperature 0, seed 42), EOS masked so
+every utterance emits exactly 4*K frames; continuous-batching scheduler + paged KV, codec decoding inside the timed region.
+One "step" = one 4-frame streaming step of every slot (4 hipGraph replays of the batched frame + the codec chunks they complete).
+The timed region is the whole job: prompt upload (PCIe, ~20 MB) + batched prefill + K steps + codec tail.
+value = audio seconds generated per wall second, summed over ranks (weak scaling: the same 64 utterances per GPU; BASELINE
+configs[3] = 512 utterances over 8 GPUs is exactly `--gpus 8`).
+
+A config-C2 leg (single utterance, one slot, hipGraph-captured 4-frame streaming) runs after the timed region on rank 0 and supplies
+`rtf`, `first_chunk_ms_p50` and `decode_ms_per_frame` -- the latency half of BASELINE.json's metric.
+`--config c2` makes C2 the timed workload instead; `--config c5` = bf16 weights, 32 slots, voice-clone prompts.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment re-launches itself under torch.distributed.run (one rank per GPU) BEFORE
+torch or HIP is touched; under a launcher, --gpus must equal WORLD_SIZE.
 """
 import argparse
 import json
@@ -24,13 +32,63 @@ sys.path.insert(0, os.path.join(ROOT, "qwen3-tts-rust_amd", "python"))
 
 FRAME_SEC = 1920.0 / 24000.0  # 12.5 Hz codec frames [EXT]
 HBM_PEAK_GBS = 8000.0         # /opt/skills/guides/MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec
-
+I8_MFMA_PEAK_TOPS = 5000.0    # dense int8 matrix-core peak (same guide: ~5 PFLOP/s fp8/int8 dense, sparsity excluded)
+F32_MFMA_PEAK_TFLOPS = 157.3
 
 _T0 = time.time()
 
 
 def log(msg):
     print("[bench %.1fs] %s" % (time.time() - _T0, msg), file=sys.stderr, flush=True)
+
+
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=32)
+    ap.add_argument("--warmup", type=int, default=4)
+    ap.add_argument("--config", default="c3", choices=["c2", "c3", "c5"], help="timed workload (BASELINE.json configs[1] / [2] / [4])")
+    ap.add_argument("--quant", default=None, help="weights: q8_0 (default), q5_k_m, bf16 (default for c5)")
+    ap.add_argument("--model-dir", default=os.environ.get("Q3_BENCH_MODEL", "/tmp/q3tts_synth_full"))
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-codec", action="store_true")
+    ap.add_argument("--no-c2-leg", action="store_true", help="skip the single-utterance latency leg that rides along with c3 / c5")
+    ap.add_argument("--batch", type=int, default=0, help="sequence slots per GPU (default: 1 for c2, 64 for c3, 32 for c5)")
+    ap.add_argument("--requests", type=int, default=0, help="utterances per GPU (default = --batch); more than --batch queue up and are "
+                                                            "admitted by the continuous-batching scheduler as slots retire")
+    ap.add_argument("--clone", action="store_true", help="voice-clone prompt layout (implied by --config c5)")
+    ap.add_argument("--ragged", action="store_true", help="utterance lengths 50..100 %% of 4*steps frames (slots retire at different times)")
+    ap.add_argument("--stub-engine", action="store_true", help=argparse.SUPPRESS)  # CPU rehearsal of the rank logic (tests/test_dist_cpu.py)
+    args = ap.parse_args(argv)
+    if args.config == "c5":
+        args.clone = True
+    if args.quant is None:
+        args.quant = "bf16" if args.config == "c5" else "q8_0"
+    if args.batch <= 0:
+        args.batch = {"c2": 1, "c3": 64, "c5": 32}[args.config]
+    return args
+
+
+def launch_ranks(n, argv):
+    """--gpus N without a launcher: start N ranks (one per GPU) as a CHILD process tree and return its exit code.  Runs before torch /
+    HIP is initialised in this process (a process that has touched the GPU must not exec or fork GPU work)."""
+    port = 29400 + (os.getpid() % 500)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(n), "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def reduce_over_ranks(dist, torch, dev, audio_s, elapsed):
+    """whole-job aggregate: SUM of the audio seconds every rank generated, MAX of the elapsed times (ranks may hold different work)"""
+    if dist is None:
+        return audio_s, elapsed
+    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    a = torch.tensor([audio_s], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX)
+    dist.all_reduce(a, op=dist.ReduceOp.SUM)
+    return float(a.item()), float(t.item())
 
 
 def ensure_model(model_dir, quant):
@@ -50,79 +108,182 @@ def build_prompt(assets, spk_emb, n_text=32, seed=42):
     return assets.build_core(text, lang_id=2055, spk_emb=spk_emb)
 
 
-def cpu_baseline(model_dir, quant_dir, prompt, threads=4):
-    """Oracle (CPU restatement, oracle/) timed with the reference's threading (llama threads capped at 4,
-    /root/reference/src/models/llama/mod.rs:420-428): a BOUNDED sample, extrapolated to the 128-frame utterance."""
+def host_cpu_info():
+    model, phys, logical = "unknown", None, os.cpu_count()
+    try:
+        cores = set()
+        phys_id = core_id = None
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name") and model == "unknown":
+                model = line.split(":", 1)[1].strip()
+            elif line.startswith("physical id"):
+                phys_id = line.split(":", 1)[1].strip()
+            elif line.startswith("core id"):
+                core_id = line.split(":", 1)[1].strip()
+            elif not line.strip():
+                if phys_id is not None and core_id is not None:
+                    cores.add((phys_id, core_id))
+                phys_id = core_id = None
+        phys = len(cores) or None
+    except OSError:
+        pass
+    try:
+        usable = len(os.sched_getaffinity(0))
+    except AttributeError:
+        usable = logical
+    return {"model": model, "physical_cores": phys, "logical_cpus": logical, "usable_cpus": usable}
+
+
+def cpu_baseline(model_dir, quant_dir, prompt, codec_path):
+    """The CPU restatement (oracle/, kind "port") of the same single-utterance loop, timed on this box's host cores the way the reference
+    threads it: talker + predictor on 4 threads (llama.cpp thread cap, /root/reference/src/models/llama/mod.rs:420-428), the codec decoder
+    on its own thread (engine.rs:495) -- so the AR loop and the decoder overlap and the utterance takes max(AR, codec) -- plus an
+    all-usable-cores figure.  BOUNDED sample (a few prefill tokens + frames), extrapolated to the 43-row / 128-frame utterance of C2."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import q3oracle as O
-    eng = O.Engine(os.path.join(model_dir, quant_dir), None, threads)
-    n_pre, n_fr = 16, 12
-    eng.generate(prompt[-2:], max_steps=0)  # page the mmapped weights in (untimed)
-    t0 = time.time()
-    eng.generate(prompt[-n_pre:], max_steps=0)
-    t_pre = (time.time() - t0) / n_pre  # seconds per prefill token
-    t0 = time.time()
-    eng.generate(prompt[-n_pre:], max_steps=n_fr)
-    t_frame = (time.time() - t0 - t_pre * n_pre) / n_fr
-    eng.close()
-    frames = 128
-    total = t_pre * prompt.shape[0] + t_frame * frames
-    return {"value": frames * FRAME_SEC / total, "unit": "audio_s/s", "cores": threads, "kind": "port",
-            "rtf": total / (frames * FRAME_SEC),
-            "sample": "oracle AR loop (no codec): %d prefill tokens + %d frames timed (%.3f s/token, %.3f s/frame), "
-                      "extrapolated to %d prompt rows + %d frames" % (n_pre, n_fr, t_pre, t_frame, prompt.shape[0], frames)}
+    info = host_cpu_info()
+    n_pre, n_fr, frames = 8, 8, 128
+    out = {"unit": "audio_s/s", "kind": "port", "host": info}
+
+    def ar_rate(threads):
+        eng = O.Engine(os.path.join(model_dir, quant_dir), None, threads)
+        eng.generate(prompt[-2:], max_steps=0)  # page the mmapped weights in (untimed)
+        t0 = time.time()
+        eng.generate(prompt[-n_pre:], max_steps=0)
+        t_pre = (time.time() - t0) / n_pre
+        t0 = time.time()
+        eng.generate(prompt[-n_pre:], max_steps=n_fr)
+        t_frame = max((time.time() - t0 - t_pre * n_pre) / n_fr, 1e-9)
+        eng.close()
+        return t_pre, t_frame
+
+    def codec_rate(threads):
+        if not (codec_path and os.path.exists(codec_path)):
+            return None
+        oc = O.Codec(codec_path)
+        oc.reset()
+        rng = np.random.default_rng(3)
+        oc.decode(rng.integers(0, 2048, (1, 16)))          # warm
+        t0 = time.time()
+        oc.decode(rng.integers(0, 2048, (4, 16)))          # one 4-frame chunk, as the chunker hands it over
+        t = (time.time() - t0) / 4
+        oc.close()
+        return t
+
+    t_pre4, t_frame4 = ar_rate(4)
+    t_codec = codec_rate(4)
+    ar_total = t_pre4 * prompt.shape[0] + t_frame4 * frames
+    codec_total = (t_codec or 0.0) * frames
+    total4 = max(ar_total, codec_total) + (4 * (t_codec or 0.0))   # overlapped threads + the last chunk's decode after the loop
+    out.update({"value": frames * FRAME_SEC / total4, "cores": 4 + (1 if t_codec else 0), "rtf": total4 / (frames * FRAME_SEC)})
+    allc = max(1, min(int(info["usable_cpus"] or 4), 16))   # 16 = a one-GPU box's CPU share on this pool
+    extra = ""
+    if allc > 4:
+        t_preA, t_frameA = ar_rate(allc)
+        totalA = max(t_preA * prompt.shape[0] + t_frameA * frames, codec_total) + 4 * (t_codec or 0.0)
+        out["all_cores"] = {"value": frames * FRAME_SEC / totalA, "cores": allc, "rtf": totalA / (frames * FRAME_SEC),
+                            "s_per_prefill_token": t_preA, "s_per_frame": t_frameA}
+        extra = "; all-cores run: %d threads" % allc
+    out["sample"] = ("oracle single-utterance loop, config-C2 shape: %d prefill tokens + %d AR frames timed on 4 threads (%.3f s/token, "
+                     "%.3f s/frame)%s, codec %s; utterance = max(AR, codec thread) extrapolated to %d prompt rows + %d frames%s"
+                     % (n_pre, n_fr, t_pre4, t_frame4,
+                        "" if t_codec is None else " + one 4-frame codec chunk (%.3f s/frame)" % t_codec,
+                        "on its own thread" if t_codec is not None else "absent", prompt.shape[0], frames, extra))
+    return out
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=32)
-    ap.add_argument("--warmup", type=int, default=4)
-    ap.add_argument("--quant", default="q8_0")
-    ap.add_argument("--model-dir", default=os.environ.get("Q3_BENCH_MODEL", "/tmp/q3tts_synth_full"))
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-codec", action="store_true")
-    ap.add_argument("--batch", type=int, default=1, help="sequence slots per GPU (1 = config C2, 64 = config C3)")
-    ap.add_argument("--requests", type=int, default=0, help="utterances per GPU (default = --batch); more than --batch queue up and are "
-                                                            "admitted by the continuous-batching scheduler as slots retire")
-    ap.add_argument("--clone", action="store_true", help="config C5 prompts: voice-clone layout (62 reference frames + 24 reference-text ids + 32 text "
-                                                          "ids = 133 rows), 4 distinct voices round-robin")
-    ap.add_argument("--ragged", action="store_true", help="utterance lengths 50..100 %% of 4*steps frames (slots retire at different times)")
-    args = ap.parse_args()
+def load_traffic(kernel_key):
+    """HBM bytes per launch of the roofline kernel from the tracked PMC summary (profiles/hbm_traffic_latest.json, written by
+    scripts/make_hbm_traffic_md.py from separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes); None when no entry matches."""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    try:
+        tab = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    ent = tab.get(kernel_key)
+    return float(ent["read_bytes"] + ent.get("write_bytes", 0.0)) if ent else None
 
+
+class StubEngine:
+    """CPU stand-in used only by tests/test_dist_cpu.py to rehearse the launcher + rank aggregation (no GPU, no library)."""
+
+    class _Assets:
+        def build_core(self, text, lang_id=2055, spk_emb=None):
+            return np.zeros((11 + len(text), 2048), np.float32)
+
+        def build_clone(self, text, rc, rt, se):
+            return np.zeros((133, 2048), np.float32)
+
+    def __init__(self, rank):
+        self.assets = StubEngine._Assets()
+        self.rank = rank
+
+    def generate_batch(self, prompts, max_steps=8, **kw):
+        ms = max_steps if isinstance(max_steps, (list, tuple)) else [max_steps] * len(prompts)
+        time.sleep(0.02 * (1 + self.rank))
+        return [{"codes": np.zeros((m, 16), np.int32), "pcm": None, "prefill_ms": 1.0, "first_chunk_ms": 2.0, "total_ms": 3.0} for m in ms]
+
+    def stats(self):
+        return {"frame_loop_ms": 1.0, "graph_frames": 1, "slot_frames": 1.0, "prefill_ms": 0.0, "codec_ms": 0.0, "codec_calls": 0,
+                "gemv_bytes": 0.0, "gemv_ms": 0.0, "gemv_launches": 0, "gu_bytes": 0.0, "gu_ms": 0.0, "gu_launches": 0}
+
+    def reset_stats(self):
+        pass
+
+    def set_instrument(self, on):
+        pass
+
+    def bytes_per_step(self, batch, ctx):
+        return 0.0
+
+    def close(self):
+        pass
+
+
+def main(argv=None):
+    args = parse_args(argv)
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args.gpus, sys.argv[1:] if argv is None else argv))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus != world:
+        raise SystemExit("bench.py: --gpus %d does not match WORLD_SIZE %d (launch one rank per GPU, or drop the launcher and let "
+                         "--gpus start the ranks)" % (args.gpus, world))
     import torch
+    stub = args.stub_engine
     dist = None
     if world > 1 or os.environ.get("Q3_BENCH_FORCE_DIST") == "1":  # the knob rehearses the RCCL path with a single rank
         import torch.distributed as dist
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    dev = torch.device("cuda", local_rank)
+        if stub:
+            dist.init_process_group("gloo")
+        else:
+            torch.cuda.set_device(local_rank)
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    dev = torch.device("cpu") if stub else torch.device("cuda", local_rank)
+
+    def sync():
+        if not stub:
+            torch.cuda.synchronize()
 
     log("torch imported")
-    if local_rank == 0:
+    if local_rank == 0 and not stub:
         ensure_model(args.model_dir, args.quant)
     log("model ready")
     if dist:
         dist.barrier()
 
-    import q3tts as Q
     quant_dir = {"q8_0": "gguf_q8_0", "q5_k_m": "gguf_q5_k_m", "bf16": "gguf_bf16"}.get(args.quant, "gguf")
     codec_path = os.path.join(args.model_dir, "onnx", "q3tts_codec.gguf")
-    have_codec = (not args.no_codec) and os.path.exists(codec_path)
+    have_codec = (not args.no_codec) and (stub or os.path.exists(codec_path))
     max_frames = 4 * max(args.steps, args.warmup, 2)
-    try:
+    if stub:
+        eng = StubEngine(rank)
+        Q = None
+    else:
+        import q3tts as Q
         eng = Q.Engine(args.model_dir, args.quant, max_batch=args.batch, max_prompt=1024, max_steps=max_frames, load_codec=have_codec,
                        device=local_rank)
-    except Q.Q3Error as ex:
-        if have_codec and "codec" in str(ex):
-            have_codec = False
-            eng = Q.Engine(args.model_dir, args.quant, max_batch=args.batch, max_prompt=1024, max_steps=max_frames, load_codec=False,
-                           device=local_rank)
-        else:
-            raise
 
     # speaker embedding: rank 0 owns the voice file; the ONE collective of the path is its broadcast over RCCL/xGMI
     spk = torch.zeros(2048, dtype=torch.float32, device=dev)
@@ -136,25 +297,26 @@ def main():
     log("engine up, prompt rows %d" % prompt.shape[0])
 
     n_req = max(args.requests, args.batch)
+    clone_info = None
     if args.clone:  # clone prompts, 4 voices (the speaker embeddings are perturbations of the broadcast one; codes are seeded)
         voices = []
         for v in range(4):
             vr = np.random.default_rng(1000 + v)
             voices.append(((spk_emb * (1.0 - 0.1 * v) + 0.01 * vr.standard_normal(2048)).astype(np.float32), vr.integers(0, 2048, 62 * 16).astype(np.int32),
                            vr.integers(0, 4000, 24).astype(np.int32)))
-        # reference-audio front end (row a16, onnx.rs:167-320): log-mel of a seeded 5 s chirp + noise per voice on the device.  The codec /
-        # speaker encoder graphs that would consume it are not in the container (SURVEY 8a row a17 -> next row f-2), so the reference
-        # codes and speaker embeddings above stay synthetic; the mel time is reported, not hidden.
-        import q3tts as _q
-        tt = np.arange(5 * 24000) / 24000.0
-        ref_audio = [(0.4 * np.sin(2 * np.pi * (200 + 600 * v + 2500 * tt) * tt) + 0.02 * np.random.default_rng(7 + v).standard_normal(tt.size)).astype(np.float32)
-                     for v in range(4)]
-        _q.mel(ref_audio[0])  # warm-up (filter bank + twiddles are built on first use)
-        t0 = time.perf_counter()
-        mels = [_q.mel(a) for a in ref_audio]
-        clone_info = {"ref_audio_s_per_voice": 5.0, "voices": 4, "mel_frames_per_voice": int(mels[0].shape[0]),
-                      "mel_ms_per_voice_incl_pcie": 1e3 * (time.perf_counter() - t0) / 4,
-                      "encoders": "absent from the container (SURVEY 8a a17 / 8f f-2): reference codes and speaker embeddings are seeded synthetic"}
+        if not stub:
+            # reference-audio front end (row a16, onnx.rs:167-320): log-mel of a seeded 5 s chirp + noise per voice on the device.  The codec /
+            # speaker encoder graphs that would consume it are not in the container (SURVEY 8a row a17 -> next row f-2), so the reference
+            # codes and speaker embeddings above stay synthetic; the mel time is reported, not hidden.
+            tt = np.arange(5 * 24000) / 24000.0
+            ref_audio = [(0.4 * np.sin(2 * np.pi * (200 + 600 * v + 2500 * tt) * tt) + 0.02 * np.random.default_rng(7 + v).standard_normal(tt.size)).astype(np.float32)
+                         for v in range(4)]
+            Q.mel(ref_audio[0])  # warm-up (filter bank + twiddles are built on first use)
+            t0 = time.perf_counter()
+            mels = [Q.mel(a) for a in ref_audio]
+            clone_info = {"ref_audio_s_per_voice": 5.0, "voices": 4, "mel_frames_per_voice": int(mels[0].shape[0]),
+                          "mel_ms_per_voice_incl_pcie": 1e3 * (time.perf_counter() - t0) / 4,
+                          "encoders": "absent from the container (SURVEY 8a a17 / 8f f-2): reference codes and speaker embeddings are seeded synthetic"}
         prompts = []
         for i in range(n_req):
             se, rc, rt = voices[i % 4]
@@ -164,108 +326,148 @@ def main():
         prompts = [prompt] if n_req == 1 else [build_prompt(eng.assets, spk_emb, n_text=(16, 32, 64)[i % 3], seed=42 + i) for i in range(n_req)]
     last_run = {}
 
-    def run(steps, pcm):
-        ms = [4 * steps] * n_req
-        if args.ragged:
-            ms = [max(1, int(4 * steps * (0.5 + 0.5 * ((i * 7) % 11) / 10.0))) for i in range(n_req)]
-        res = eng.generate_batch(prompts, max_steps=ms, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)
+    def run(engine, plist, steps, pcm):
+        ms = [4 * steps] * len(plist)
+        if args.ragged and len(plist) > 1:
+            ms = [max(1, int(4 * steps * (0.5 + 0.5 * ((i * 7) % 11) / 10.0))) for i in range(len(plist))]
+        res = engine.generate_batch(plist, max_steps=ms, temperature=0.0, seed=42, mask_eos=True, want_pcm=pcm)
         last_run["frames"] = sum(r["codes"].shape[0] for r in res)
         last_run["first_chunk"] = [r["first_chunk_ms"] for r in res]
         assert all(r["codes"].shape[0] == m for r, m in zip(res, ms)), "EOS-masked runs must emit exactly max_steps frames"
         return res[0]
 
     if args.warmup > 0:
-        run(args.warmup, have_codec)
+        run(eng, prompts, args.warmup, have_codec)
     log("warmup done")
     eng.reset_stats()
     if dist:
         dist.barrier()
-    torch.cuda.synchronize()
+    sync()
     t0 = time.perf_counter()
-    res = run(args.steps, have_codec)
-    torch.cuda.synchronize()
+    res = run(eng, prompts, args.steps, have_codec)
+    sync()
     if dist:
         dist.barrier()
-    elapsed = time.perf_counter() - t0
-    t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    if dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    elapsed = float(t.item())
+    elapsed_local = time.perf_counter() - t0
+    audio_local = last_run["frames"] * FRAME_SEC
+    audio_s, elapsed = reduce_over_ranks(dist, torch, dev, audio_local, elapsed_local)
     st = eng.stats()
-    log("timed region done: %.3f s" % elapsed)
+    log("timed region done: %.3f s (this rank %.3f s, %.1f audio-s)" % (elapsed, elapsed_local, audio_local))
     n_frames = res["codes"].shape[0]
-    audio_s = last_run["frames"] * FRAME_SEC
     timed_first_chunk = list(last_run["first_chunk"])
 
-    out = None
     if rank == 0:
-        # first-chunk latency (submit -> first PCM chunk available, engine.rs:522-523 analogue): p50 over short utterances
-        lat = []
-        if n_req == 1:
-            for _ in range(5):
-                r = run(2, have_codec)
-                lat.append(r["first_chunk_ms"] if have_codec else r["prefill_ms"] + (r["total_ms"] - r["prefill_ms"]) / 2.0)
-        else:  # many utterances: the timed run's own per-request latencies (includes queueing behind the batched prefill)
-            lat = [v for v in timed_first_chunk if v > 0] or [0.0]
-        log("latency runs done")
-        # instrumented leg: same K steps, eager launches with a HIP-event pair around every k_gemv_q8 launch
-        eng.reset_stats()
-        eng.set_instrument(True)
-        run(args.steps, False)
-        eng.set_instrument(False)
-        si = eng.stats()
-        mean_ctx = prompt.shape[0] + 4 * args.steps / 2.0
-        step_bytes = eng.bytes_per_step(args.batch, mean_ctx)
-        fam_bytes, fam_ms, fam_n = si["gemv_bytes"] + si["gu_bytes"], si["gemv_ms"] + si["gu_ms"], si["gemv_launches"] + si["gu_launches"]
-        gemv_gbs = fam_bytes / (fam_ms * 1e-3) / 1e9 if fam_ms > 0 else 0.0
-        gu_gbs = si["gu_bytes"] / (si["gu_ms"] * 1e-3) / 1e9 if si["gu_ms"] > 0 else 0.0
         frame_ms = st["frame_loop_ms"] / max(st["graph_frames"], 1)   # one graph replay advances every active slot by a frame
+        is_float = args.quant in ("bf16", "f16", "f32")
+        workload = {"c2": "C2: single utterance per GPU, hipGraph-captured 4-frame streaming",
+                    "c3": "C3: %d concurrent utterances through %d slots per GPU, continuous-batching scheduler + paged KV" % (n_req, args.batch),
+                    "c5": "C5: voice-clone prompts (133 rows, 4 voices), %d utterances through %d slots per GPU" % (n_req, args.batch)}[args.config]
+        if args.config == "c2" and args.batch > 1:
+            workload = "custom: %d utterances through %d slots per GPU" % (n_req, args.batch)
         out = {
-            "metric": "audio-seconds generated per second (aggregate over GPUs); RTF = n_gpus/value",
-            "value": world * audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "metric": "audio-seconds generated per second (aggregate over GPUs) = concurrent real-time streams; RTF and first-chunk latency from the single-utterance leg",
+            "value": audio_s / elapsed, "unit": "audio_s/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": {"bf16": "f32 x bf16 weights", "f16": "f32 x f16 weights"}.get(args.quant, "i8"), "data": "synthetic",
-            "config": {"workload": (("C5-style voice-clone prompts, " if args.clone else "") + ("C2 single utterance per GPU" if n_req == 1 else "C3-style %d utterances through %d slots per GPU (continuous batching)" % (n_req, args.batch))) + ", Q3TTS-1.7B-synth %s, greedy, hipGraph 4-frame streaming steps" % args.quant.upper(),
-                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames": int(n_frames), "batch_per_gpu": args.batch, "requests_per_gpu": n_req, "ragged": bool(args.ragged),
+            "config": {"workload": workload + ", Q3TTS-1.7B-synth %s, greedy, EOS masked" % args.quant.upper(),
+                       "quant": args.quant, "n_prompt": int(prompt.shape[0]), "frames_per_utterance": int(n_frames), "batch_per_gpu": args.batch,
+                       "requests_per_gpu": n_req, "ragged": bool(args.ragged),
                        "mean_graph_width": st["slot_frames"] / max(st["graph_frames"], 1),
                        "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
-            "rtf": elapsed / audio_s,
-            "first_chunk_ms_p50": statistics.median(lat),
-            "decode_ms_per_frame": frame_ms,
+            "audio_s_total": audio_s, "elapsed_s": elapsed,
+            "batch_rtf": elapsed / audio_s,
+            "batch_first_chunk_ms_p50": statistics.median([v for v in timed_first_chunk if v > 0] or [0.0]),
+            "batch_decode_ms_per_step_frame": frame_ms,
             "prefill_ms": st["prefill_ms"],
-            "codec_ms_per_chunk": (st["codec_ms"] / st["codec_calls"]) if st["codec_calls"] else None,
-            "frame_hbm_frac": (step_bytes / (frame_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if frame_ms > 0 else None,
-            # dominant kernel by algorithmic bytes: the talker's fused gate/up kernel (26.7 MB of Q8_0 weights per launch, 28 per frame)
-            "roofline": {"bound": "hbm", "kernel": "q3::k_gateup_swiglu<1, 8> (talker: norm + gate/up GEMV + SwiGLU + quant; %d launches)" % si["gu_launches"],
-                         "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
-                         "avg_launch_us": 1e3 * si["gu_ms"] / max(si["gu_launches"], 1),
-                         "bytes_per_launch": si["gu_bytes"] / max(si["gu_launches"], 1),
-                         "traffic": 27.04e6,  # profiles/r01_hbm_traffic_pmc.md: FETCH_SIZE 13202 KiB x 2 (gfx950 correction) per launch
-                         "method": "HIP-event pair around every launch in an eager replay of the same K steps (adds ~1-2 us over rocprof's kernel time)",
-                         "family_all_gemv": {"achieved": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS, "launches": fam_n,
-                                             "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1)}},
         }
-        if args.clone:
+        if clone_info:
             out["config"]["ref_audio_front_end"] = clone_info
-        if args.batch > 1:
-            # batched steps run the weight-streaming GEMM kernels (k_gemm_q8_mfma / k_gemm_q8_tok); the instrumented family is the line
-            fam_name = "q3::k_gemm_float_mfma16 / k_gemm_float_mfma (f32 MFMA, K = 1)" if args.quant in ("bf16", "f16", "f32") else "q3::k_gemm_q8_mfma + k_gemv_q8*"
-            out["roofline"].update({"kernel": "%s family (batched step; %d launches)" % (fam_name, fam_n), "achieved": gemv_gbs,
-                                    "frac": gemv_gbs / HBM_PEAK_GBS, "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1),
-                                    "bytes_per_launch": fam_bytes / max(fam_n, 1), "traffic": None})
-            if args.quant in ("bf16", "f16", "f32"):
-                # float weights: f32 activations x f32-widened weights on the K = 1 f32 MFMA (exact fma chains) -- at `batch` tokens per launch
-                # the matrix pipe, not HBM, is the nearer roof: 2 flops per weight element per token against the 157.3 TFLOP/s f32 MFMA peak
+        if stub:
+            print(json.dumps(out))
+            eng.close()
+            if dist:
+                dist.barrier()
+                dist.destroy_process_group()
+            return
+        # ---- instrumented leg: the same K steps, eager launches with a HIP-event pair (on the engine's stream) around every weight-streaming launch
+        eng.reset_stats()
+        eng.set_instrument(True)
+        run(eng, prompts, args.steps, False)
+        eng.set_instrument(False)
+        si = eng.stats()
+        mean_ctx = float(np.mean([p.shape[0] for p in prompts])) + 4 * args.steps / 2.0
+        step_bytes = eng.bytes_per_step(args.batch, mean_ctx)
+        out["frame_hbm_frac"] = (step_bytes / (frame_ms * 1e-3) / 1e9) / HBM_PEAK_GBS if frame_ms > 0 else None
+        fam_bytes, fam_ms, fam_n = si["gemv_bytes"] + si["gu_bytes"], si["gemv_ms"] + si["gu_ms"], si["gemv_launches"] + si["gu_launches"]
+        fam_gbs = fam_bytes / (fam_ms * 1e-3) / 1e9 if fam_ms > 0 else 0.0
+        gu_gbs = si["gu_bytes"] / (si["gu_ms"] * 1e-3) / 1e9 if si["gu_ms"] > 0 else 0.0
+        gu_us = 1e3 * si["gu_ms"] / max(si["gu_launches"], 1)
+        gu_bpl = si["gu_bytes"] / max(si["gu_launches"], 1)
+        ntok = args.batch
+        if args.batch == 1:
+            kname, kkey = "q3::k_gateup_swiglu<1, 8> (talker: norm + gate/up GEMV + SwiGLU + quant)", "k_gateup_swiglu<1, 8>"
+        elif is_float:
+            kname, kkey = "q3::k_gateup_float_mfma16 / k_gemm_float_mfma (talker gate/up, K = 1 f32 MFMA chains)", "k_gateup_float"
+        else:
+            kname, kkey = "q3::k_gemm_q8_mfma<GU> (talker gate/up GEMM + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_q8_mfma<true>"
+        # dominant kernel by algorithmic bytes AND by share of the batched step: the talker's gate/up launch (12288 rows x 2048 x 1.0625 B
+        # = 26.7 MB of Q8_0 weights per launch, 28 launches per frame step)
+        roof = {"bound": "hbm", "kernel": "%s; %d launches" % (kname, si["gu_launches"]),
+                "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
+                "avg_launch_us": gu_us, "bytes_per_launch": gu_bpl, "traffic": load_traffic(kkey),
+                "method": "HIP-event pair on the engine's stream around every launch in an eager replay of the same K steps (adds ~2 us over rocprofv3's kernel time)",
+                "family_all_weight_streaming_launches": {"achieved": fam_gbs, "frac": fam_gbs / HBM_PEAK_GBS, "launches": fam_n,
+                                                         "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1), "bytes_per_launch": fam_bytes / max(fam_n, 1)}}
+        if args.batch > 1 and si["gu_ms"] > 0:
+            if is_float:
                 esz = 4 if args.quant == "f32" else 2
-                tfl = 2.0 * (fam_bytes / esz) * args.batch / (fam_ms * 1e-3) / 1e12 if fam_ms > 0 else 0.0
-                out["roofline"].update({"bound": "mfma", "achieved": tfl, "peak": 157.3, "unit": "TFLOP/s", "frac": tfl / 157.3,
-                                        "hbm_view": {"achieved_gbs": gemv_gbs, "frac": gemv_gbs / HBM_PEAK_GBS}})
+                tfl = 2.0 * (si["gu_bytes"] / esz) * ntok / (si["gu_ms"] * 1e-3) / 1e12
+                roof.update({"bound": "mfma", "achieved": tfl, "peak": F32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": tfl / F32_MFMA_PEAK_TFLOPS,
+                             "hbm_view": {"achieved_gbs": gu_gbs, "frac": gu_gbs / HBM_PEAK_GBS}})
+            else:
+                # int8 view: 2 ops per weight element per token on the int8 matrix cores; at <= 256 tokens per launch HBM is the nearer roof
+                tops = 2.0 * (si["gu_bytes"] / 1.0625) * ntok / (si["gu_ms"] * 1e-3) / 1e12
+                roof["mfma_view"] = {"achieved_tops": tops, "peak_tops": I8_MFMA_PEAK_TOPS, "frac": tops / I8_MFMA_PEAK_TOPS, "tokens_per_launch": ntok}
+        out["roofline"] = roof
         log("instrumented leg done")
+        # ---- config-C2 leg: the latency half of the metric (single utterance, one slot) ----
+        c2_prompt = prompt if (n_req == 1 or args.clone) else build_prompt(eng.assets, spk_emb)
+        if args.batch == 1:
+            e1, own = eng, False
+        elif not args.no_c2_leg:
+            e1, own = Q.Engine(args.model_dir, args.quant, max_batch=1, max_prompt=1024, max_steps=max_frames, load_codec=have_codec, device=local_rank), True
+        else:
+            e1, own = None, False
+        if e1 is not None:
+            if own:
+                run(e1, [c2_prompt], max(args.warmup, 1), have_codec)
+            e1.reset_stats()
+            sync()
+            t1 = time.perf_counter()
+            run(e1, [c2_prompt], args.steps, have_codec)
+            sync()
+            c2_elapsed = time.perf_counter() - t1
+            s1 = e1.stats()
+            lat = []
+            for _ in range(5):
+                r = run(e1, [c2_prompt], 2, have_codec)
+                lat.append(r["first_chunk_ms"] if have_codec else r["prefill_ms"] + (r["total_ms"] - r["prefill_ms"]) / 2.0)
+            c2_audio = 4 * args.steps * FRAME_SEC
+            out["rtf"] = c2_elapsed / c2_audio
+            out["first_chunk_ms_p50"] = statistics.median(lat)
+            out["decode_ms_per_frame"] = s1["frame_loop_ms"] / max(s1["graph_frames"], 1)
+            out["c2_leg"] = {"workload": "C2: single utterance, 1 slot, %d frames, hipGraph 4-frame steps, codec included" % (4 * args.steps),
+                             "audio_s_per_s": c2_audio / c2_elapsed, "prefill_ms": s1["prefill_ms"], "n_prompt": int(c2_prompt.shape[0]),
+                             "frame_hbm_frac": (e1.bytes_per_step(1, c2_prompt.shape[0] + 2.0 * args.steps) / (out["decode_ms_per_frame"] * 1e-3) / 1e9) / HBM_PEAK_GBS}
+            if own:
+                e1.close()
+            log("C2 leg done")
         if world == 1 and not args.no_cpu_baseline:
             try:
-                out["cpu_baseline"] = cpu_baseline(args.model_dir, quant_dir, prompt)
+                out["cpu_baseline"] = cpu_baseline(args.model_dir, quant_dir, build_prompt(eng.assets, spk_emb), codec_path if have_codec else None)
             except Exception as ex:  # the oracle is optional test infrastructure; report, do not hide
                 out["cpu_baseline"] = {"value": None, "unit": "audio_s/s", "cores": 4, "kind": "port", "sample": "failed: %s" % ex}
+            log("cpu baseline done")
         print(json.dumps(out))
     eng.close()
     if dist:

@@ -58,3 +58,29 @@ def test_single_process_passthrough():
     e, c, t = broadcast_voice(np.ones(2048, np.float32), [1, 2], None)
     assert e.shape == (2048,) and c.tolist() == [1, 2] and t.size == 0
     assert shard_requests(5, 0, 1) == [0, 1, 2, 3, 4]
+
+
+def test_bench_launcher_and_rank_aggregation_world2():
+    """bench.py --gpus 2 with no launcher in the environment must START two ranks (torch.distributed.run), and its whole-job value must be
+    SUM(audio seconds over ranks) / MAX(elapsed over ranks).  Runs the real bench.py rank logic over gloo with a stub engine (no GPU)."""
+    import json
+    import subprocess
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--stub-engine",
+                        "--requests", "5", "--batch", "4", "--ragged"], env=env, capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["scaling"] == "weak"
+    # every rank ran the same 5 ragged requests of the stub: frames = sum(max(1, int(12 * (0.5 + 0.5 * ((i * 7) % 11) / 10)))) per rank
+    frames = sum(max(1, int(12 * (0.5 + 0.5 * ((i * 7) % 11) / 10.0))) for i in range(5))
+    assert abs(out["audio_s_total"] - 2 * frames * 0.08) < 1e-9
+    assert abs(out["value"] - out["audio_s_total"] / out["elapsed_s"]) < 1e-9
+    assert out["elapsed_s"] >= 0.04          # rank 1's stub sleeps 40 ms: the MAX over ranks, not rank 0's 20 ms
+
+
+def test_bench_rejects_mismatched_world():
+    import subprocess
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--stub-engine"], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "does not match WORLD_SIZE" in (r.stderr + r.stdout)

@@ -627,3 +627,24 @@ def test_llama_abi_replay_matches_oracle(gpu, oracle, tiny_model, vivian, tmp_pa
     subprocess.check_call([os.path.join(pkg, "ref_replay"), os.path.join(tiny_model, "gguf_q8_0"), pf, str(prompt.shape[0]), "6", cf, "1"], cwd=pkg)
     got = np.fromfile(cf, np.int32).reshape(-1, 16)
     assert np.array_equal(got, oc)
+
+
+def test_two_engines_keep_their_own_assets(gpu, synth_tool, tiny_model):
+    """q3tts_engine_assets returns a handle that lives inside its engine (a thread-local view made the first engine read the
+    second engine's tables): two engines over different assets files, interleaved calls, one destroyed before the other is used again."""
+    other = os.environ.get("Q3_TINY_MODEL2", "/tmp/q3tts_pytest_tiny_seed99")
+    if not os.path.exists(os.path.join(other, ".complete")):
+        subprocess.check_call([synth_tool, "--out", other, "--preset", "tiny", "--quant", "q8_0", "--seed", "99"])
+        open(os.path.join(other, ".complete"), "w").write("ok")
+    e1 = gpu.Engine(tiny_model, "q8_0", max_batch=1, max_steps=8, load_codec=False)
+    a1 = e1.assets.text_embedding(1234).copy()
+    e2 = gpu.Engine(other, "q8_0", max_batch=1, max_steps=8, load_codec=False)
+    a2 = e2.assets.text_embedding(1234).copy()
+    assert not np.array_equal(a1, a2)
+    assert np.array_equal(e1.assets.text_embedding(1234), a1) and np.array_equal(e2.assets.text_embedding(1234), a2)
+    f1 = gpu.Assets(os.path.join(tiny_model, "gguf_q8_0", "qwen3_assets.gguf"))
+    assert np.array_equal(f1.text_embedding(1234), a1)
+    f1.close()
+    e2.close()
+    assert np.array_equal(e1.assets.text_embedding(1234), a1) and np.array_equal(e1.assets.tts_pad(), e1.assets.text_embedding(151671))
+    e1.close()
