@@ -91,6 +91,30 @@ __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __rest
 template <bool GU, bool SM>
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+template <bool GU, int ABL = 0>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+template <bool GU>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gemm_q8_wave(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out,
+               int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+static int wave_form_min();
+// Which form serves a launch.  Measured on MI355X (scripts/ubench_gemm.hip, profiles/r02_ubench_gemm.txt): at 64 tokens the first form (two
+// workgroups per CU, phases of different workgroups overlap) and the second (one pass, no conversions, 2 waves per SIMD) tie per launch
+// (talker gate/up 17.6 vs 18.0 us) and the first wins the 64-slot step (7.46 vs 7.79 ms); from 128 tokens the second form's single pass
+// over the activations is ahead.  The wave-per-tile form needs >= ~1500 waves and is bound by activation re-reads through L2 (as many
+// activation bytes as weight bytes per tile); it is opt-in (Q3_GEMM_WAVE_MIN).  Q3_GEMM_V1=1 / Q3_GEMM_V2=1 force one form everywhere.
+static bool gemm_v1(int ntok) {
+    static const int mode = [] { const char* a = std::getenv("Q3_GEMM_V1"); const char* b = std::getenv("Q3_GEMM_V2"); return (a && a[0] == '1') ? 1 : (b && b[0] == '1') ? 2 : 0; }();
+    return mode == 1 || (mode == 0 && ntok < 128);
+}
+// token tiles per launch dimension z of the second form: one workgroup (8 waves) per CU at 2 waves per SIMD, so aim at >= 2 workgroups per CU
+static int mfma2_ztiles(int rowgroups, int nsseg, int ntok) {
+    const int ntiles = (ntok + 31) / 32;
+    static const int target = [] { const char* e = std::getenv("Q3_MFMA2_WGS"); return e ? atoi(e) : 512; }();
+    int z = (target + rowgroups * nsseg - 1) / (rowgroups * nsseg);
+    return z < 1 ? 1 : (z > ntiles ? ntiles : z);
+}
 static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
@@ -238,6 +262,16 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
+        if (!gemm_v1(ntok) && (long)rgs * nsseg * ((ntok + 31) / 32) >= wave_form_min()) {
+            hipLaunchKernelGGL((k_gemm_q8_wave<false>), dim3((rgs + 3) / 4, nsseg, (ntok + 31) / 32), dim3(256), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0,
+                               (int8_t*)nullptr, (uint16_t*)nullptr);
+            return;
+        }
+        if (!gemm_v1(ntok)) {
+            hipLaunchKernelGGL((k_gemm_q8_mfma2<false>), dim3(rgs, nsseg, mfma2_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+            return;
+        }
         if (q8_scale_mfma())
             hipLaunchKernelGGL((k_gemm_q8_mfma<false, true>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
                                out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
@@ -272,6 +306,14 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
 bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok) {
     if (wgu.rg_type || ntok < 16 || (wgu.K != 1024 && wgu.K != 2048) || (ff & 31)) return false;
     const int rgs = ff / 32, ntiles = (ntok + 31) / 32;
+    if (!gemm_v1(ntok) && (long)rgs * ntiles >= wave_form_min()) {
+        hipLaunchKernelGGL((k_gemm_q8_wave<true>), dim3((rgs + 3) / 4, 1, ntiles), dim3(256), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+        return true;
+    }
+    if (!gemm_v1(ntok)) {
+        hipLaunchKernelGGL((k_gemm_q8_mfma2<true>), dim3(rgs, 1, mfma2_ztiles(rgs, 1, ntok)), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+        return true;
+    }
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
     if (q8_scale_mfma()) hipLaunchKernelGGL((k_gemm_q8_mfma<true, true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
@@ -493,6 +535,292 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
         }
     }
 }
+
+// -----------------------------------------------------------------------------------------------------
+// Second form of the batched int8 GEMM (default; Q3_GEMM_V1=1 restores the kernel above for A/B runs).  Same spec arithmetic, same
+// launch geometry and LDS segment combine; what changed is everything that kept the first form far from both of its roofs:
+//   * float(idot) without v_cvt_f32_i32: the int8 MFMA accumulates on top of the bit pattern of 1/(2 pi) = 0x3E22F983 -- an INLINE constant
+//     of the ISA, so the C operand costs no registers -- whose binade [2^-3, 2^-2) has room for -2 292 099 ... +6 096 508 mantissa steps
+//     (|idot| <= 128 * 127 * 32 = 520 192).  The accumulator, read as f32, is then c0 + idot * 2^-26 exactly; c0 is subtracted (exact: the
+//     result has <= 20 significant bits) and the factor 2^26 is folded into the scale tile (a power of two: exact).  fma(idot * 2^-26,
+//     2^26 * dw * dx, acc) rounds the same real number idot * dw * dx + acc once, so the bits are those of the spec's fma.  Per 32 x 32 tile
+//     and block: 8 v_pk_add_f32 + 8 v_pk_fma_f32 instead of 16 v_cvt + 8 v_pk_fma.
+//   * gate/up form: both weight tiles are resident (64 VGPRs), so a token tile is loaded once and both products finish in one pass --
+//     no second weight-load latency behind the first pass, no gate sums parked in LDS.
+//   * all 8 activation blocks of a token tile are fetched at once and the NEXT tile's blocks before the current tile is computed; the
+//     kernel is built for 2 waves per SIMD (256 VGPRs) -- latency is hidden by what a wave has in flight, not by more waves.
+// -----------------------------------------------------------------------------------------------------
+#define Q3_GEMM2_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+// ABL: ablation switches for scripts/ubench_gemm.hip only (1 = no matrix/vector work, 2 = no activation loads, 4 = no weight loads,
+// 8 = no LDS combine / epilogue stores); production code instantiates ABL = 0
+template <bool GU, int ABL>
+__global__ void Q3_GEMM2_BUDGET k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq,
+                                                uint16_t* __restrict__ ad) {
+    constexpr int NM = GU ? 2 : 1;
+    __shared__ float red[NM][8][32][32]; // [matrix][segment][token][row]: lanes of a half write / read consecutive words
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    int nsg = nseg - sseg * 8;
+    if (nsg > 8) nsg = 8;
+    const bool active = seg < nseg; // wave-uniform
+    const int ntiles = (ntok + 31) >> 5;
+    constexpr int MAGIC = 0x3E22F983;
+    const float c0 = __int_as_float(MAGIC);
+    const f32x2v negc0 = f32x2v{-c0, -c0};
+    i32x4v wv[NM][8];
+    uint4 dwv[NM];
+    if (active) {
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+            int row = row0 + blockIdx.x * 32 + r + q * ff;
+            if (row > w.Npad - 1) row = w.Npad - 1;
+            const int rg = row >> 5, r32 = row & 31;
+            const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+#pragma unroll
+            for (int i = 0; i < 8; i++) wv[q][i] = (ABL & 4) ? i32x4v{lane, i, q, 1} : *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
+            dwv[q] = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+        }
+    }
+    // A operand: this lane feeds token (lane & 31), k-half (lane >> 5); dx: that token's 8 block scales
+    i32x4v av[8];
+    uint4 dxa = make_uint4(0, 0, 0, 0);
+    auto load_x = [&](int tt, i32x4v* a, uint4& dx) {
+        int atok = tt * 32 + r;
+        if (atok > ntok - 1) atok = ntok - 1;
+        const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+#pragma unroll
+        for (int i = 0; i < 8; i++) a[i] = (ABL & 2) ? i32x4v{lane, i, tt, 2} : *reinterpret_cast<const i32x4v*>(xp + i * 32);
+        dx = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8);
+    };
+    if (active) load_x(blockIdx.z, av, dxa);
+    // B operand of the scale outer product: lanes 0..31 feed block 2p, lanes 32..63 block 2p + 1, with the 2^26 of the magic offset folded in
+    float ew[NM][4];
+#pragma unroll
+    for (int q = 0; q < NM; q++)
+#pragma unroll
+        for (int p = 0; p < 4; p++) ew[q][p] = active ? h2f(half ? half_of(dwv[q], 2 * p + 1) : half_of(dwv[q], 2 * p)) * 67108864.0f : 0.0f;
+#pragma unroll 1
+    for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z) {
+        const int tok0 = tt * 32, tn = tt + gridDim.z;
+        i32x4v avn[8];
+        uint4 dxn = make_uint4(0, 0, 0, 0);
+        if (active && tn < ntiles) load_x(tn, avn, dxn); // next tile in flight while this one is computed
+        if (active) {
+            // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
+            f32x2v acc[NM][8];
+#pragma unroll
+            for (int q = 0; q < NM; q++)
+#pragma unroll
+                for (int g = 0; g < 8; g++) acc[q][g] = f32x2v{0.0f, 0.0f};
+            if (ABL & 1) {
+#pragma unroll
+                for (int q = 0; q < NM; q++)
+#pragma unroll
+                    for (int g = 0; g < 8; g++) acc[q][g] = f32x2v{__int_as_float(av[g][q] ^ wv[q][g][1]), __int_as_float(av[g][2] ^ wv[q][g][3])};
+            } else
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float ex = h2f(half ? half_of(dxa, 2 * p + 1) : half_of(dxa, 2 * p));
+#pragma unroll
+                for (int q = 0; q < NM; q++) {
+                    f32x32q D;
+#pragma unroll
+                    for (int g = 0; g < 32; g++) D[g] = 0.0f;
+                    D = __builtin_amdgcn_mfma_f32_32x32x1f32(ex, ew[q][p], D, 0, 0, 0); // exact: f16 x f16 x 2^26
+#pragma unroll
+                    for (int i2 = 0; i2 < 2; i2++) {
+                        const int i = 2 * p + i2;
+                        i32x16 c;
+#pragma unroll
+                        for (int g = 0; g < 16; g++) c[g] = MAGIC;
+                        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[q][i], c, 0, 0, 0);
+#pragma unroll
+                        for (int g4 = 0; g4 < 4; g4++) {
+                            const int o = 16 * i2 + 4 * g4;
+                            const f32x2v ca = f32x2v{__int_as_float(c[4 * g4]), __int_as_float(c[4 * g4 + 1])} + negc0;
+                            const f32x2v cb = f32x2v{__int_as_float(c[4 * g4 + 2]), __int_as_float(c[4 * g4 + 3])} + negc0;
+                            acc[q][2 * g4] = __builtin_elementwise_fma(ca, f32x2v{D[o], D[o + 1]}, acc[q][2 * g4]);
+                            acc[q][2 * g4 + 1] = __builtin_elementwise_fma(cb, f32x2v{D[o + 2], D[o + 3]}, acc[q][2 * g4 + 1]);
+                        }
+                    }
+                }
+            }
+            if (ABL & 8) { // keep the results alive with one conditional store
+                float sum = 0.0f;
+#pragma unroll
+                for (int q = 0; q < NM; q++)
+#pragma unroll
+                    for (int g = 0; g < 16; g++) sum += acc[q][g >> 1][g & 1];
+                if (sum == 1.2345f) red[0][0][0][0] = sum;
+            } else
+#pragma unroll
+            for (int q = 0; q < NM; q++)
+#pragma unroll
+                for (int g = 0; g < 16; g++) red[q][wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[q][g >> 1][g & 1];
+        }
+        __syncthreads();
+        if (!(ABL & 8))
+        for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
+            const int m = t >> 5, rr = t & 31, tok = tok0 + m;
+            float S = red[0][0][m][rr];
+            for (int s2 = 1; s2 < nsg; s2++) S = S + red[0][s2][m][rr];
+            if (!GU) {
+                const int orow = blockIdx.x * 32 + rr;
+                if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+            } else {
+                float U = red[NM - 1][0][m][rr];
+                for (int s2 = 1; s2 < nsg; s2++) U = U + red[NM - 1][s2][m][rr];
+                const float y = q3_swiglu(S, U);
+                float amax = q3_fabsf(y);
+                amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+                amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
+                const float dd = amax / 127.0f;
+                const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+                if (tok < ntok) {
+                    aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
+                    if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+                }
+            }
+        }
+        __syncthreads(); // red is rewritten by the next tile
+        if (tn < ntiles) {
+#pragma unroll
+            for (int i = 0; i < 8; i++) av[i] = avn[i];
+            dxa = dxn;
+        }
+    }
+}
+
+// -----------------------------------------------------------------------------------------------------
+// Third form, for launches with enough (row group, token tile) pairs to fill the chip on their own (talker gate/up from 64 tokens, every
+// talker matrix from ~128 tokens, prefill chunks): ONE WAVE owns a 32-row x 32-token tile over a whole super-segment.  The 8 segment
+// chains run back to back in the wave's registers and the segment sums are added in spec order in registers too, so nothing goes through
+// LDS and there is no barrier: scripts/ubench_gemm.hip shows the segment-per-wave forms above spend as long in their LDS combine + epilogue
+// (4 us of 15 for the talker gate/up at 64 tokens, 17 of 46 at 256) as in the matrix pipe.  Weights and activations of the next segment are
+// in flight while the current one is computed (2 waves per SIMD, 256 VGPRs).  Gate/up form: the wave runs the gate row group, then the
+// matching up row group, and finishes SwiGLU + the 32-row int8 quantisation in registers (the 32 rows of a block are the 32 lanes of a
+// half-wave: five DPP steps).  The 4 waves of a workgroup take 4 consecutive row groups of the SAME token tile, so the activation lines
+// they all read are fetched into the CU's L1 once.  Arithmetic per (row, token): unchanged (same chains, same order) -> same bits.
+// -----------------------------------------------------------------------------------------------------
+template <bool GU>
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gemm_q8_wave(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out,
+               int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg0 = sseg * 8;
+    int nsg = nseg - seg0;
+    if (nsg > 8) nsg = 8;
+    const int rgi = blockIdx.x * 4 + wave;                  // row group of this wave (of the gate half in the gate/up form)
+    if (rgi * 32 >= nrows) return;                          // wave-uniform; the kernel has no barrier
+    const int tok0 = blockIdx.z * 32;
+    constexpr int MAGIC = 0x3E22F983;
+    const float c0 = __int_as_float(MAGIC);
+    const f32x2v negc0 = f32x2v{-c0, -c0};
+    int atok = tok0 + r;
+    if (atok > ntok - 1) atok = ntok - 1;
+    const int8_t* xbase = xq + (size_t)atok * w.K + half * 16;
+    const uint16_t* dxbase = xd + (size_t)atok * nb;
+    constexpr int NM = GU ? 2 : 1;
+    f32x2v S[NM][8];
+#pragma unroll
+    for (int q = 0; q < NM; q++) {
+        int row = row0 + rgi * 32 + r + q * ff;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const uint8_t* wbase = w.qs + (size_t)rg * nb * 1024 + half * 512 + r32 * 16;
+        const uint16_t* dwbase = w.sc + ((size_t)rg * nseg * 32 + r32) * 8;
+        i32x4v wv[8], av[8];
+        uint4 dwv, dxa;
+#pragma unroll
+        for (int i = 0; i < 8; i++) wv[i] = *reinterpret_cast<const i32x4v*>(wbase + ((size_t)seg0 * 8 + i) * 1024);
+#pragma unroll
+        for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xbase + seg0 * 256 + i * 32);
+        dwv = *reinterpret_cast<const uint4*>(dwbase + (size_t)seg0 * 256);
+        dxa = *reinterpret_cast<const uint4*>(dxbase + seg0 * 8);
+#pragma unroll 1
+        for (int s = 0; s < nsg; s++) {
+            const bool more = s + 1 < nsg; // wave-uniform
+            const int sn = seg0 + s + (more ? 1 : 0);
+            // the next segment's operands are re-loaded block by block into the registers the matrix instructions have just consumed: every
+            // wave keeps ~16 KB in flight at all times, which across >= 1500 resident waves is what the HBM stream needs (Little's law),
+            // without a second register set
+            // (branch-free: the last segment re-loads itself -- 1/8 more L2 reads, but the body stays one basic block, which the scheduler needs
+            // to keep each pair's matrix instructions next to their vector chains instead of issuing all twelve first and spilling)
+            const uint4 dwn = *reinterpret_cast<const uint4*>(dwbase + (size_t)sn * 256);
+            const uint4 dxn = *reinterpret_cast<const uint4*>(dxbase + sn * 8);
+            f32x2v acc[8];
+#pragma unroll
+            for (int g = 0; g < 8; g++) acc[g] = f32x2v{0.0f, 0.0f};
+#pragma unroll
+            for (int p = 0; p < 4; p++) {
+                const float ex = h2f(half ? half_of(dxa, 2 * p + 1) : half_of(dxa, 2 * p));
+                const float ewp = h2f(half ? half_of(dwv, 2 * p + 1) : half_of(dwv, 2 * p)) * 67108864.0f;
+                f32x32q D;
+#pragma unroll
+                for (int g = 0; g < 32; g++) D[g] = 0.0f;
+                D = __builtin_amdgcn_mfma_f32_32x32x1f32(ex, ewp, D, 0, 0, 0);
+#pragma unroll
+                for (int i2 = 0; i2 < 2; i2++) {
+                    const int i = 2 * p + i2;
+                    i32x16 c;
+#pragma unroll
+                    for (int g = 0; g < 16; g++) c[g] = MAGIC;
+                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
+                    wv[i] = *reinterpret_cast<const i32x4v*>(wbase + ((size_t)sn * 8 + i) * 1024);
+                    av[i] = *reinterpret_cast<const i32x4v*>(xbase + sn * 256 + i * 32);
+#pragma unroll
+                    for (int g4 = 0; g4 < 4; g4++) {
+                        const int o = 16 * i2 + 4 * g4;
+                        const f32x2v ca = f32x2v{__int_as_float(c[4 * g4]), __int_as_float(c[4 * g4 + 1])} + negc0;
+                        const f32x2v cb = f32x2v{__int_as_float(c[4 * g4 + 2]), __int_as_float(c[4 * g4 + 3])} + negc0;
+                        acc[2 * g4] = __builtin_elementwise_fma(ca, f32x2v{D[o], D[o + 1]}, acc[2 * g4]);
+                        acc[2 * g4 + 1] = __builtin_elementwise_fma(cb, f32x2v{D[o + 2], D[o + 3]}, acc[2 * g4 + 1]);
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0); // keep the scheduler from issuing every pair's matrix instructions up front (their result tiles would not fit)
+            }
+            if (s == 0) {
+#pragma unroll
+                for (int g = 0; g < 8; g++) S[q][g] = acc[g];
+            } else {
+#pragma unroll
+                for (int g = 0; g < 8; g++) S[q][g] = S[q][g] + acc[g]; // segment sums in order (spec S3)
+            }
+            dwv = dwn; dxa = dxn;
+        }
+    }
+    // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
+    if (!GU) {
+        const int orow = rgi * 32 + r;
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int tok = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S[0][g >> 1][g & 1];
+        }
+    } else {
+#pragma unroll
+        for (int g = 0; g < 16; g++) {
+            const int tok = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
+            const float y = q3_swiglu(S[0][g >> 1][g & 1], S[NM - 1][g >> 1][g & 1]);
+            float amax = q3_fabsf(y);
+            amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+            amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
+            const float dd = amax / 127.0f;
+            const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+            if (tok < ntok) {
+                aq[(size_t)tok * ff + rgi * 32 + r] = (int8_t)(int)q3_rintf(y * id);
+                if (r == 0) ad[(size_t)tok * (ff >> 5) + rgi] = f2h(dd);
+            }
+        }
+    }
+}
+// which launches take the wave-per-tile form: enough independent (row group, token tile, super-segment) waves to occupy the SIMDs
+static int wave_form_min() { static const int v = [] { const char* e = std::getenv("Q3_GEMM_WAVE_MIN"); return e ? atoi(e) : (1 << 30); }(); return v; }
 
 // =====================================================================================================
 // residual + RMSNorm + int8 activation quantisation (spec S4, S2, S9).  One wave per token: lane l owns
