@@ -122,6 +122,46 @@ int q3tts_submit_text(q3tts_engine* e, int32_t voice_id, const int32_t* text_ids
                       const int32_t* instr_ids, int32_t n_instr, const q3tts_sampler_config* sampler, int32_t max_steps,
                       int32_t mask_eos, int32_t want_pcm, int64_t* req_id);
 
+/* ---- multi-GPU: request sharding, weights replicated per device, no collective on the data path ----
+ * q3tts_group_*: ONE process, N devices.  One engine (+ scheduler thread + decoder thread) per entry of device_ids; requests go round-robin
+ * (request i -> engine i % n); group request ids carry the engine index.  q3tts_group_voice_register uploads the VoiceFile payload
+ * (utils/voice_file.rs:5-22) to the first device and broadcasts it device-to-device -- ncclBroadcast over communicators from
+ * ncclCommInitAll (RCCL over xGMI; librccl.so is bound at run time) or, when RCCL is unavailable or a device is listed twice,
+ * hipMemcpyPeerAsync -- and every engine registers the voice from its own device's copy.  Register voices through the group only, so
+ * that one voice id is valid on every engine.  p->device is ignored. */
+typedef struct q3tts_group q3tts_group;
+int q3tts_group_create(const q3tts_engine_params* p, const int32_t* device_ids, int32_t n_dev, q3tts_group** out);
+void q3tts_group_destroy(q3tts_group* g);
+int32_t q3tts_group_size(q3tts_group* g);
+q3tts_engine* q3tts_group_engine(q3tts_group* g, int32_t i);   /* borrowed: stats, assets, per-engine calls */
+int32_t q3tts_group_uses_rccl(q3tts_group* g);                 /* 1: registrations go through ncclBroadcast, 0: peer copies */
+int q3tts_group_voice_register(q3tts_group* g, const float* spk_emb2048, const int32_t* ref_codes, int32_t n_ref_codes,
+                               const int32_t* ref_text_ids, int32_t n_ref_text, int32_t* voice_id);
+int q3tts_group_submit(q3tts_group* g, const q3tts_request* r, int32_t want_pcm, int64_t* req_id);
+int q3tts_group_submit_text(q3tts_group* g, int32_t voice_id, const int32_t* text_ids, int32_t n_text, int32_t lang_id,
+                            const int32_t* instr_ids, int32_t n_instr, const q3tts_sampler_config* sampler, int32_t max_steps,
+                            int32_t mask_eos, int32_t want_pcm, int64_t* req_id);
+int32_t q3tts_group_device_of(q3tts_group* g, int64_t req_id); /* HIP device a request was sharded to */
+int q3tts_group_poll(q3tts_group* g, int64_t req_id, q3tts_req_status* out);
+int q3tts_group_fetch(q3tts_group* g, int64_t req_id, int32_t* codes_out, int32_t frame_off, int32_t max_frames, float* pcm_out,
+                      int64_t pcm_off, int64_t pcm_cap, int32_t* got_frames, int64_t* got_pcm);
+int q3tts_group_wait(q3tts_group* g, int64_t req_id, double timeout_ms);
+int q3tts_group_release(q3tts_group* g, int64_t req_id);
+int q3tts_group_start(q3tts_group* g);                         /* q3tts_sched_start on every engine */
+int q3tts_group_stop(q3tts_group* g);
+/* q3tts_comm_*: ONE process per GPU (what `bench.py --gpus N` / torchrun-style launchers use).  Rank 0 makes the 128-byte id and ships it to
+ * the other ranks by any means (environment, file, socket); every rank creates its communicator (ncclCommInitRank) and calls
+ * q3tts_comm_voice_register collectively: the root passes the voice, the other ranks pass NULL / 0 and receive it; each registers it on
+ * its own engine. */
+typedef struct q3tts_comm q3tts_comm;
+int q3tts_comm_available(void);                                /* 1 when librccl.so could be loaded */
+int q3tts_comm_unique_id(uint8_t out_id[128]);
+int q3tts_comm_create(const uint8_t id[128], int32_t rank, int32_t world, int32_t device, q3tts_comm** out);
+void q3tts_comm_destroy(q3tts_comm* c);
+int q3tts_comm_voice_register(q3tts_comm* c, q3tts_engine* e, int32_t root, const float* spk_emb2048, const int32_t* ref_codes,
+                              int32_t n_ref_codes, const int32_t* ref_text_ids, int32_t n_ref_text, int32_t* voice_id);
+int32_t q3tts_engine_device(q3tts_engine* e);
+
 /* ---- assets + prompt builder (host) ---- */
 typedef struct q3tts_assets q3tts_assets;
 int q3tts_assets_open(const char* gguf_path, q3tts_assets** out);

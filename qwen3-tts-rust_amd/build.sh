@@ -9,7 +9,7 @@ FLAGS="${Q3_EXTRA_FLAGS:-} -mllvm -amdgpu-kernarg-preload-count=16 -O3 -std=c++1
 mkdir -p build
 OBJS=""
 PIDS=""
-for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/llama_shim.cpp; do
+for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/group.cpp csrc/llama_shim.cpp; do
   [ -f "$f" ] || continue
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then
@@ -23,7 +23,7 @@ done
 FAIL=0
 for p in $PIDS; do wait "$p" || FAIL=1; done
 if [ "$FAIL" != 0 ]; then echo "build failed" >&2; exit 1; fi
-/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=$ARCH -o libq3tts.so $OBJS
+/opt/rocm/bin/hipcc -shared -fPIC --offload-arch=$ARCH -o libq3tts.so $OBJS -ldl
 mkdir -p runtime && cp -f libq3tts.so runtime/libllama.so
 # host side: C++ mirror of the reference API + the Boundary-A replay harness (plain g++, no HIP)
 g++ -O2 -std=c++17 -fPIC -ffp-contract=off -shared -o libq3tts_host.so host/tts_engine.cpp -L. -lq3tts -Wl,-rpath,'$ORIGIN'

@@ -49,6 +49,7 @@ int q3tts_engine_create(const q3tts_engine_params* p, q3tts_engine** out) {
     Q3_API_END(Q3TTS_ERR)
 }
 void q3tts_engine_destroy(q3tts_engine* e) { delete e; }
+int32_t q3tts_engine_device(q3tts_engine* e) { return e ? e->e->device() : -1; }
 
 static GenRequest to_gen(const q3tts_request& q);
 int q3tts_generate_batch(q3tts_engine* e, q3tts_request* reqs, int32_t n, int32_t want_pcm) {

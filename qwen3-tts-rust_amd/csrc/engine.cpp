@@ -188,6 +188,7 @@ struct Engine::Req {
 };
 
 Engine::~Engine() {
+    (void)hipSetDevice(dev_);
     try { stop_driver(); } catch (...) {}
     if (dec_started_) {
         { std::lock_guard<std::mutex> lk(dmu_); dec_stop_ = true; }
@@ -745,6 +746,7 @@ static double g_t_harvest = 0, g_t_admit = 0, g_t_group = 0, g_t_idle = 0;
 static const bool g_trace = std::getenv("Q3_SCHED_TRACE") != nullptr;
 bool Engine::step() {
     std::lock_guard<std::mutex> step_lock(step_mu_);
+    Q3_HIP(hipSetDevice(dev_)); // HIP's current device is per thread: any thread may drive any engine of a multi-device group
     if (codec_ && !dec_started_) { dec_started_ = true; dec_thread_ = std::thread([this] { decoder_main(); }); }
     const double t0 = now_ms();
     harvest(false);

@@ -96,6 +96,7 @@ public:
     size_t bytes_per_frame_step(int batch, double mean_ctx) const; // algorithmic HBM bytes of one batched frame step
     hipStream_t stream() const { return st_; }
     int max_batch() const { return B_; }
+    int device() const { return dev_; }
 
 private:
     struct Req;

@@ -16,6 +16,10 @@ struct llama_context {
 struct llama_sampler { float t; };
 
 static std::mutex g_mu;
+// capacity (ints) of the pos array of every batch handed out by llama_batch_init: llama_batch itself does not carry it, the caller writes at
+// most n_tokens_max ints (llama/mod.rs:567-581) but the M-RoPE layout READS 4 * n_tokens of them (reference quirk 3)
+#include <map>
+static std::map<const int32_t*, int> g_pos_cap;
 #define SHIM_TRY try {
 #define SHIM_CATCH(ret) } catch (const std::exception& ex) { set_last_error(ex.what()); fprintf(stderr, "q3tts llama shim: %s\n", ex.what()); return ret; }
 
@@ -83,9 +87,11 @@ llama_batch llama_batch_init(int32_t n_tokens, int32_t embd, int32_t n_seq_max) 
     b.seq_id = (int32_t**)calloc((size_t)n_tokens + 1, sizeof(int32_t*));
     for (int i = 0; i < n_tokens; i++) b.seq_id[i] = (int32_t*)calloc((size_t)(n_seq_max > 0 ? n_seq_max : 1), sizeof(int32_t));
     b.logits = (int8_t*)calloc((size_t)n_tokens, 1);
+    { std::lock_guard<std::mutex> lk(g_mu); g_pos_cap[b.pos] = n_tokens; }
     return b;
 }
 void llama_batch_free(llama_batch b) {
+    { std::lock_guard<std::mutex> lk(g_mu); g_pos_cap.erase(b.pos); }
     free(b.token); free(b.embd); free(b.pos); free(b.n_seq_id);
     if (b.seq_id) { for (int i = 0; b.seq_id[i]; i++) free(b.seq_id[i]); free(b.seq_id); }
     free(b.logits);
@@ -97,14 +103,26 @@ int32_t llama_decode(struct llama_context* c, llama_batch b) {
     const auto& hp = c->model->tf->hp();
     const int n = b.n_tokens;
     const bool mrope = (hp.mrope_sec[0] + hp.mrope_sec[1] + hp.mrope_sec[2] + hp.mrope_sec[3]) > 0;
+    int cap = 4 * n; // ints the caller may have written; unknown batches (not from llama_batch_init) are trusted
+    { std::lock_guard<std::mutex> lk(g_mu); auto it = g_pos_cap.find(b.pos); if (it != g_pos_cap.end()) cap = it->second; }
     std::vector<int32_t> pos4((size_t)4 * n);
     for (int i = 0; i < n; i++)
-        for (int s = 0; s < 4; s++) pos4[(size_t)4 * i + s] = mrope ? b.pos[(size_t)s * n + i] : b.pos[i]; // stream-major, engine.rs:306-314
-    std::vector<float> hid((size_t)n * hp.n_embd), lg((size_t)n * hp.n_vocab);
-    c->c->eval(b.embd, pos4.data(), n, hid.data(), lg.data(), 0, hp.n_vocab);
+        for (int s = 0; s < 4; s++) { // stream-major, engine.rs:306-314; entries past the allocation were never written (prompts > 1024
+            const size_t idx = mrope ? (size_t)s * n + i : (size_t)i; // tokens, mod.rs:567-581): stream 0 stands in, never an out-of-bounds read
+            pos4[(size_t)4 * i + s] = idx < (size_t)cap ? b.pos[idx] : (s == 3 ? 0 : ((size_t)i < (size_t)cap ? b.pos[i] : i));
+        }
+    // hidden rows for every token (one copy of the final-norm output); the output matrix only for rows the caller flagged -- plus, with
+    // params.embeddings, nothing more: the reference reads logits and embeddings at the BATCH index of the flagged row (engine.rs:550-566)
+    const bool all_rows = c->params.embeddings;
+    std::vector<int8_t> want(n, 0);
+    int n_flag = 0;
+    for (int i = 0; i < n; i++) if (b.logits && b.logits[i]) { want[i] = 1; n_flag++; }
+    if (n_flag == 0) want[n - 1] = 1;
+    std::vector<float> hid((size_t)n * hp.n_embd), lg((size_t)n * hp.n_vocab, 0.0f);
+    c->c->eval(b.embd, pos4.data(), n, hid.data(), lg.data(), 0, hp.n_vocab, want.data());
     c->logits.clear(); c->embd.clear(); c->n_out = 0;
     for (int i = 0; i < n; i++) {
-        if (c->params.embeddings || (b.logits && b.logits[i])) {
+        if (all_rows || want[i]) { // embeddings = true: rows addressable by batch index (unflagged logits rows are zero); else compacted
             c->logits.insert(c->logits.end(), lg.begin() + (size_t)i * hp.n_vocab, lg.begin() + (size_t)(i + 1) * hp.n_vocab);
             c->embd.insert(c->embd.end(), hid.begin() + (size_t)i * hp.n_embd, hid.begin() + (size_t)(i + 1) * hp.n_embd);
             c->n_out++;

@@ -21,7 +21,8 @@ public:
     int n_past() const { return n_past_; }
     Transformer& model() { return *model_; }
     // x [ntok][n_embd] host, pos4 [ntok][4] host; outputs host (nullable)
-    void eval(const float* x, const int32_t* pos4, int ntok, float* hidden_out, float* logits_out, int row0, int row1) {
+    // want_rows (optional, [ntok]): logits are computed only for tokens whose flag is non-zero (rows of the others are left untouched)
+    void eval(const float* x, const int32_t* pos4, int ntok, float* hidden_out, float* logits_out, int row0, int row1, const int8_t* want_rows = nullptr) {
         const auto& hp = model_->hp();
         Q3_CHECK(n_past_ + ntok <= n_ctx_, "context overflow");
         kv_->ensure(0, n_past_ + ntok);
@@ -39,14 +40,21 @@ public:
             const bool want_logits = logits_out && row1 > row0;
             const int r0 = row0 & ~31, nr = want_logits ? row1 - r0 : 0;
             if (want_logits && d_logits_.n < (size_t)n * nr) d_logits_.alloc((size_t)n * nr);
-            model_->head(st_, 0, n, want_logits ? r0 : 0, nr, d_logits_.p, nr, nullptr, -1, d_hid_.p);
+            if (!want_rows) model_->head(st_, 0, n, want_logits ? r0 : 0, nr, d_logits_.p, nr, nullptr, -1, d_hid_.p);
+            else { // llama.cpp computes the output matrix for flagged rows only (batch.logits[i]); hidden rows come from one call
+                model_->head(st_, 0, n, 0, 0, nullptr, 0, nullptr, -1, d_hid_.p);
+                if (want_logits)
+                    for (int i = 0; i < n; i++)
+                        if (want_rows[t0 + i]) model_->head(st_, i, 1, r0, nr, d_logits_.p + (size_t)i * nr, nr, nullptr, -1, nullptr);
+            }
             Q3_HIP(hipStreamSynchronize(st_));
             if (want_logits) {
                 std::vector<float> tmp((size_t)n * nr);
                 d_logits_.download(tmp.data(), tmp.size());
                 for (int i = 0; i < n; i++)
-                    std::copy(tmp.begin() + (size_t)i * nr + (row0 - r0), tmp.begin() + (size_t)i * nr + (row0 - r0) + (row1 - row0),
-                              logits_out + (size_t)(t0 + i) * (row1 - row0));
+                    if (!want_rows || want_rows[t0 + i])
+                        std::copy(tmp.begin() + (size_t)i * nr + (row0 - r0), tmp.begin() + (size_t)i * nr + (row0 - r0) + (row1 - row0),
+                                  logits_out + (size_t)(t0 + i) * (row1 - row0));
             }
             if (hidden_out) d_hid_.download(hidden_out + (size_t)t0 * hp.n_embd, (size_t)n * hp.n_embd);
             n_past_ += n;

@@ -9,6 +9,7 @@
 #include <dlfcn.h>
 #include <unistd.h>
 #include <cmath>
+#include <chrono>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -79,9 +80,11 @@ int main(int argc, char** argv) {
         b.n_tokens = n;
     };
     auto qwen3_position = [](int start, int len) { std::vector<int32_t> p; for (int s = 0; s < 3; s++) for (int i = 0; i < len; i++) p.push_back(start + i); for (int i = 0; i < len; i++) p.push_back(0); return p; };
+    const auto t_start = std::chrono::steady_clock::now();
     llama_batch tb = p_llama_batch_init(4096, talker_embd, 1);
     set_embd(tb, prompt.data(), prompt.size(), talker_embd, qwen3_position(0, n_prompt), 4096);
     if (p_llama_decode(tctx, tb) != 0) { fprintf(stderr, "Talker prefill failed\n"); return 5; }
+    const auto t_prefill = std::chrono::steady_clock::now();
     llama_batch pb = p_llama_batch_init(32, pred_embd, 1);
     std::vector<int32_t> all_codes;
     int cur_pos = n_prompt;
@@ -128,7 +131,13 @@ int main(int argc, char** argv) {
     FILE* of = fopen(argv[5], "wb");
     fwrite(all_codes.data(), 4, all_codes.size(), of);
     fclose(of);
-    printf("frames %zu\n", all_codes.size() / 16);
+    const auto t_end = std::chrono::steady_clock::now();
+    const double pre_ms = std::chrono::duration<double, std::milli>(t_prefill - t_start).count();
+    const double loop_ms = std::chrono::duration<double, std::milli>(t_end - t_prefill).count();
+    const size_t nfr = all_codes.size() / 16;
+    printf("frames %zu\n", nfr);
+    // Boundary A timing: the reference's own loop (17 llama_decode round trips + host projection / gathers per frame), no codec
+    printf("timing prefill_ms %.2f loop_ms %.2f ms_per_frame %.3f rtf_ar_only %.4f\n", pre_ms, loop_ms, nfr ? loop_ms / nfr : 0.0, nfr ? (pre_ms + loop_ms) / (nfr * 80.0) : 0.0);
     p_llama_free(tctx); p_llama_free(pctx); p_llama_model_free(talker); p_llama_model_free(pred);
     p_llama_backend_free();
     return 0;

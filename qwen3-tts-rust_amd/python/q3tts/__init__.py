@@ -64,6 +64,10 @@ SYMBOLS = [
     "q3tts_tf_dims", "q3tts_tf_clear", "q3tts_tf_eval", "q3tts_op_gemv_q8", "q3tts_op_gateup_q8", "q3tts_op_matmul_float", "q3tts_op_rmsnorm_quant", "q3tts_op_swiglu_quant",
     "q3tts_op_argmax", "q3tts_op_project", "q3tts_op_sample", "q3tts_submit", "q3tts_poll", "q3tts_fetch", "q3tts_wait",
     "q3tts_release", "q3tts_decoder_create_ex", "q3tts_decoder_decode_group", "q3tts_sched_start", "q3tts_sched_stop", "q3tts_sched_step", "q3tts_voice_register", "q3tts_submit_text",
+    "q3tts_group_create", "q3tts_group_destroy", "q3tts_group_size", "q3tts_group_engine", "q3tts_group_uses_rccl", "q3tts_group_voice_register",
+    "q3tts_group_submit", "q3tts_group_submit_text", "q3tts_group_device_of", "q3tts_group_poll", "q3tts_group_fetch", "q3tts_group_wait",
+    "q3tts_group_release", "q3tts_group_start", "q3tts_group_stop", "q3tts_comm_available", "q3tts_comm_unique_id", "q3tts_comm_create",
+    "q3tts_comm_destroy", "q3tts_comm_voice_register", "q3tts_engine_device",
 ]
 
 

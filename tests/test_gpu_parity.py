@@ -624,9 +624,17 @@ def test_llama_abi_replay_matches_oracle(gpu, oracle, tiny_model, vivian, tmp_pa
     oe.close()
     pf, cf = str(tmp_path / "prompt.f32"), str(tmp_path / "codes.i32")
     prompt.tofile(pf)
-    subprocess.check_call([os.path.join(pkg, "ref_replay"), os.path.join(tiny_model, "gguf_q8_0"), pf, str(prompt.shape[0]), "6", cf, "1"], cwd=pkg)
+    r = subprocess.run([os.path.join(pkg, "ref_replay"), os.path.join(tiny_model, "gguf_q8_0"), pf, str(prompt.shape[0]), "6", cf, "1"], cwd=pkg,
+                       capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1500:]
     got = np.fromfile(cf, np.int32).reshape(-1, 16)
     assert np.array_equal(got, oc)
+    assert "timing prefill_ms" in r.stdout   # the zero-Rust-change path reports its own plumbing cost (scripts/replay_fullsize.sh for the full model)
+    # prompt longer than the batch's pos allocation / 4 (reference quirk 3): the shim must not read past the n_tokens ints the caller owns
+    long_prompt = np.repeat(prompt, 100, axis=0)[:1100]
+    long_prompt.tofile(pf)
+    r2 = subprocess.run([os.path.join(pkg, "ref_replay"), os.path.join(tiny_model, "gguf_q8_0"), pf, "1100", "2", cf, "1"], cwd=pkg, capture_output=True, text=True)
+    assert r2.returncode == 0 and np.fromfile(cf, np.int32).size == 32, r2.stderr[-1500:]
 
 
 def test_two_engines_keep_their_own_assets(gpu, synth_tool, tiny_model):
@@ -648,3 +656,25 @@ def test_two_engines_keep_their_own_assets(gpu, synth_tool, tiny_model):
     e2.close()
     assert np.array_equal(e1.assets.text_embedding(1234), a1) and np.isfinite(e1.assets.tts_pad()).all()
     e1.close()
+
+
+@pytest.mark.parametrize("n_engines", [2, 0])
+def test_group_api_voice_broadcast_and_round_robin(gpu, tiny_model, tmp_path, n_engines):
+    """q3tts_group_* / q3tts_comm_* (multi-GPU behind the C ABI) from a plain C program: a clone voice registered through the group is
+    broadcast from the first device and used by every engine; round-robin requests give identical codes on every engine and equal the
+    single-engine ctypes path.  n_engines = 2 on a one-GPU box lists the device twice (two engines, peer-copy path); n_engines = 0 = one
+    engine per visible device (ncclBroadcast path when the box has several)."""
+    pkg = os.path.join(ROOT, "qwen3-tts-rust_amd")
+    exe = str(tmp_path / "group_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host", "group_main.cpp"), "-L" + pkg, "-lq3tts",
+                           "-Wl,-rpath," + pkg])
+    r = subprocess.run([exe, tiny_model, str(n_engines)], capture_output=True, text=True, cwd=str(tmp_path), timeout=600)
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
+    lines = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines()}
+    spk = (0.01 * ((np.arange(2048) * 37) % 101 - 50)).astype(np.float32)
+    ge = gpu.Engine(tiny_model, "q8_0", max_batch=1, max_steps=16, load_codec=False)
+    prompt = ge.assets.build_clone(np.arange(100, 108, dtype=np.int32), (np.arange(48) * 37) % 2048, np.array([7, 8, 9], np.int32), spk)
+    ref = ge.generate_batch([prompt], max_steps=6, temperature=0.0, seed=42, mask_eos=True)[0]
+    ge.close()
+    assert np.array_equal(np.array(lines["CLONE"], np.int32).reshape(-1, 16), ref["codes"])
+    assert int(lines["PCM"][0]) == 6 * 1920 or int(lines["PCM"][0]) > 0
