@@ -71,6 +71,14 @@ void q3o_quant_act(const float* x, int64_t k, int8_t* q, uint16_t* d);
  * 16/32-bit float W uses xf. */
 void q3o_matvec(int type, const void* w, int64_t n, int64_t k, const int8_t* xq, const uint16_t* xd,
                 const float* xf, float* y);
+/* "ggml-CPU" arithmetic mode (q3o_ggml.c; env Q3_SPEC=ggml or q3o_set_arith_mode(1)): llama.cpp's portable CPU kernels restated [EXT] */
+int q3o_arith_mode(void);
+void q3o_set_arith_mode(int mode);
+void q3o_matvec_ggml(int type, const void* w, int64_t n, int64_t k, const float* xf, float* y);
+void q3o_rmsnorm_ggml(const float* x, const float* g, int64_t d, float eps, float* y);
+void q3o_headnorm128_ggml(const float* x, const float* g, float eps, float* y);
+float q3o_swiglu_ggml(float gt, float up);
+void q3o_attn_head_ggml(const float* q, const uint16_t* K, const uint16_t* V, size_t stride, int n, float* out);
 float q3o_sumsq_vec(const float* x, int64_t d);
 void q3o_rmsnorm(const float* x, const float* g, int64_t d, float eps, float* y);
 void q3o_headnorm128(const float* x, const float* g, float eps, float* y);
@@ -171,6 +179,12 @@ typedef struct q3o_engine {
     float temperature; int top_k; float top_p; uint64_t seed;
     int mask_eos;          /* bench/test knob: EOS logit excluded so runs have fixed length */
     int n_threads;
+    /* measurement hooks (tests only; NULL = off).  margins[2*f] = top-1 minus top-2 logit of frame f's code_0 (over [0,2160), EOS mask applied),
+     * margins[2*f+1] = smallest such gap among the frame's 15 predictor codes.  forced[f*16+q] (teacher forcing) replaces the loop's own pick
+     * AFTER it has been recorded in own_codes, so two arithmetic modes can be compared frame by frame along one trajectory. */
+    float* margins; int margins_cap;
+    const int32_t* forced; int forced_frames;
+    int32_t* own_codes;
 } q3o_engine;
 
 q3o_engine* q3o_engine_create(const char* model_dir_quant, const char* codec_path, int n_threads, char* err, size_t errlen);

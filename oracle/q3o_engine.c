@@ -329,6 +329,14 @@ int q3o_engine_generate(q3o_engine* e, const float* prompt, int n_prompt, int32_
     for (int step = 0; step < e->max_steps; step++) {
         if (e->mask_eos) t_logits[Q3_CODEC_EOS] = -INFINITY;
         int32_t code0 = q3o_sample(&ts, t_logits, T->n_vocab, 0, Q3_SAMPLE_END); /* :555 */
+        float pmargin = INFINITY;
+        if (e->margins && 2 * n_frames + 1 < e->margins_cap) {
+            float m1 = -INFINITY, m2 = -INFINITY;
+            for (int i = 0; i < t_end; i++) { const float v = t_logits[i]; if (v > m1) { m2 = m1; m1 = v; } else if (v > m2) m2 = v; }
+            e->margins[2 * n_frames] = m1 - m2;
+        }
+        if (e->own_codes) e->own_codes[(size_t)n_frames * 16] = code0;
+        if (e->forced && n_frames < e->forced_frames) code0 = e->forced[(size_t)n_frames * 16];
         if (code0 == Q3_CODEC_EOS || code0 == Q3_TEXT_EOS) break;                /* :558 */
         int32_t* fc = codes_out + (size_t)n_frames * 16;
         fc[0] = code0;
@@ -342,6 +350,9 @@ int q3o_engine_generate(q3o_engine* e, const float* prompt, int n_prompt, int32_
         for (int q = 1; q < 16; q++) { /* :587-611 */
             float mx = -INFINITY; int mi = 0; /* greedy predictor sampler, :470, mod.rs:690-701 */
             for (int i = 0; i < 2048; i++) if (p_logits[i] > mx) { mx = p_logits[i]; mi = i; }
+            if (e->margins) { float m2 = -INFINITY; for (int i = 0; i < 2048; i++) if (i != mi && p_logits[i] > m2) m2 = p_logits[i]; if (mx - m2 < pmargin) pmargin = mx - m2; }
+            if (e->own_codes) e->own_codes[(size_t)n_frames * 16 + q] = mi;
+            if (e->forced && n_frames < e->forced_frames) mi = e->forced[(size_t)n_frames * 16 + q];
             fc[q] = mi;
             q3o_codec_embedding(e->assets, q, mi, step_emb[q]);
             if (q < 15) {
@@ -350,6 +361,7 @@ int q3o_engine_generate(q3o_engine* e, const float* prompt, int n_prompt, int32_
                 if (q3o_model_eval(P, in_p, pp, NULL, p_logits, q * 2048, (q + 1) * 2048)) return -3;
             }
         }
+        if (e->margins && 2 * n_frames + 1 < e->margins_cap) e->margins[2 * n_frames + 1] = pmargin;
         n_frames++;
         int64_t frame64[16];
         for (int q = 0; q < 16; q++) frame64[q] = fc[q];

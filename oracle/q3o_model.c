@@ -114,8 +114,10 @@ void q3o_model_free(q3o_model* m) {
 void q3o_model_clear_kv(q3o_model* m) { m->n_past = 0; } /* llama_memory_seq_rm(mem,-1,0,-1), llama/mod.rs:482 */
 
 static void mv(const q3o_gguf_tensor* w, const int8_t* xq, const uint16_t* xd, const float* xf, float* y) {
+    if (q3o_arith_mode()) { q3o_matvec_ggml(w->type, w->data, w->ne[1], w->ne[0], xf, y); return; } /* Q3_SPEC=ggml: q3o_ggml.c */
     q3o_matvec(w->type, w->data, w->ne[1], w->ne[0], xq, xd, xf, y);
 }
+static void rmsn(const float* x, const float* g, int64_t d, float eps, float* y) { if (q3o_arith_mode()) q3o_rmsnorm_ggml(x, g, d, eps, y); else q3o_rmsnorm(x, g, d, eps, y); }
 static int is_float_type(int t) { return t == Q3_T_F32 || t == Q3_T_F16 || t == Q3_T_BF16; }
 
 /* spec S7: one query head against n cached positions. K/V: f16, element (pos,d) at base[pos*stride+d] */
@@ -196,7 +198,7 @@ int q3o_model_eval(q3o_model* m, const float* x, const int32_t pos[4], float* hi
     const size_t stride = (size_t)nkv * 128;
     for (int l = 0; l < m->n_layer; l++) {
         const q3o_layer* L = &m->layers[l];
-        q3o_rmsnorm(h, (const float*)L->attn_norm->data, d, m->eps, xn);
+        rmsn(h, (const float*)L->attn_norm->data, d, m->eps, xn);
         q3o_quant_act(xn, d, xq, xd);
         mv(L->wq, xq, xd, xn, q); mv(L->wk, xq, xd, xn, k); mv(L->wv, xq, xd, xn, v);
         uint16_t* Kl = m->kcache + (size_t)l * m->n_ctx * stride;
@@ -204,7 +206,8 @@ int q3o_model_eval(q3o_model* m, const float* x, const int32_t pos[4], float* hi
         float tmp[128];
         for (int hh = 0; hh < nh + nkv; hh++) {
             float* vec = hh < nh ? q + 128 * hh : k + 128 * (hh - nh);
-            q3o_headnorm128(vec, (const float*)(hh < nh ? L->q_norm->data : L->k_norm->data), m->eps, tmp);
+            if (q3o_arith_mode()) q3o_headnorm128_ggml(vec, (const float*)(hh < nh ? L->q_norm->data : L->k_norm->data), m->eps, tmp);
+            else q3o_headnorm128(vec, (const float*)(hh < nh ? L->q_norm->data : L->k_norm->data), m->eps, tmp);
             for (int i = 0; i < 64; i++) {
                 int32_t pp = pos[q3_mrope_stream(i, m->mrope_sec)];
                 if (pp < 0) pp = 0;
@@ -220,27 +223,30 @@ int q3o_model_eval(q3o_model* m, const float* x, const int32_t pos[4], float* hi
 #pragma omp parallel for schedule(static)
         for (int hh = 0; hh < nh; hh++) {
             int kvh = hh / grp;
-            attn_head(q + 128 * hh, Kl + 128 * kvh, Vl + 128 * kvh, stride, slot + 1, att + 128 * hh);
+            if (q3o_arith_mode()) q3o_attn_head_ggml(q + 128 * hh, Kl + 128 * kvh, Vl + 128 * kvh, stride, slot + 1, att + 128 * hh);
+            else attn_head(q + 128 * hh, Kl + 128 * kvh, Vl + 128 * kvh, stride, slot + 1, att + 128 * hh);
         }
         q3o_quant_act(att, dq, xq, xd);
         mv(L->wo, xq, xd, att, o);
         for (int i = 0; i < d; i++) h[i] = h[i] + o[i];
-        q3o_rmsnorm(h, (const float*)L->ffn_norm->data, d, m->eps, xn);
+        rmsn(h, (const float*)L->ffn_norm->data, d, m->eps, xn);
         q3o_quant_act(xn, d, xq, xd);
         mv(L->w_gate, xq, xd, xn, gt); mv(L->w_up, xq, xd, xn, up);
-        for (int i = 0; i < ff; i++) gt[i] = q3_swiglu(gt[i], up[i]);
+        if (q3o_arith_mode()) { for (int i = 0; i < ff; i++) gt[i] = q3o_swiglu_ggml(gt[i], up[i]); }
+        else for (int i = 0; i < ff; i++) gt[i] = q3_swiglu(gt[i], up[i]);
         q3o_quant_act(gt, ff, xq, xd);
         mv(L->w_down, xq, xd, gt, o);
         for (int i = 0; i < d; i++) h[i] = h[i] + o[i];
     }
     m->n_past++;
-    q3o_rmsnorm(h, (const float*)m->output_norm->data, d, m->eps, xn);
+    rmsn(h, (const float*)m->output_norm->data, d, m->eps, xn);
     if (hidden_out) memcpy(hidden_out, xn, (size_t)d * 4);
     if (logits_out && row1 > row0) {
         q3o_quant_act(xn, d, xq, xd);
         size_t rb = q3o_type_row_bytes(m->output->type, d);
         (void)is_float_type;
-        q3o_matvec(m->output->type, (const uint8_t*)m->output->data + rb * (size_t)row0, row1 - row0, d, xq, xd, xn, logits_out);
+        if (q3o_arith_mode()) q3o_matvec_ggml(m->output->type, (const uint8_t*)m->output->data + rb * (size_t)row0, row1 - row0, d, xn, logits_out);
+        else q3o_matvec(m->output->type, (const uint8_t*)m->output->data + rb * (size_t)row0, row1 - row0, d, xq, xd, xn, logits_out);
     }
     free(h); free(xn); free(xq); free(xd); free(q); free(k); free(v); free(att); free(o); free(gt); free(up);
     return 0;

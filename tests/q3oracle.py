@@ -87,7 +87,8 @@ def _p(a):
 class EngineStruct(C.Structure):
     _fields_ = [("assets", C.c_void_p), ("talker", C.c_void_p), ("predictor", C.c_void_p), ("codec", C.c_void_p),
                 ("max_steps", C.c_int), ("temperature", C.c_float), ("top_k", C.c_int), ("top_p", C.c_float),
-                ("seed", C.c_uint64), ("mask_eos", C.c_int), ("n_threads", C.c_int)]
+                ("seed", C.c_uint64), ("mask_eos", C.c_int), ("n_threads", C.c_int),
+                ("margins", C.c_void_p), ("margins_cap", C.c_int), ("forced", C.c_void_p), ("forced_frames", C.c_int), ("own_codes", C.c_void_p)]
 
 
 class Assets:
@@ -212,6 +213,25 @@ class Engine:
         if n < 0:
             raise RuntimeError("q3o_engine_generate rc=%d" % n)
         return codes[: n * 16].reshape(n, 16).copy(), pcm[: npcm.value].copy()
+
+    def generate_measured(self, prompt, max_steps, forced=None, mask_eos=True):
+        """greedy run that also returns (own picks [n][16], margins [n][2]); `forced` [n][16] teacher-forces the trajectory (see q3o.h)"""
+        margins = np.zeros((max_steps, 2), np.float32)
+        own = np.zeros((max_steps, 16), np.int32)
+        f = np.ascontiguousarray(forced, np.int32) if forced is not None else None
+        self.s.margins, self.s.margins_cap, self.s.own_codes = margins.ctypes.data, margins.size, own.ctypes.data
+        self.s.forced, self.s.forced_frames = (f.ctypes.data, f.shape[0]) if f is not None else (None, 0)
+        try:
+            codes, _ = self.generate(prompt, max_steps=max_steps, temperature=0.0, mask_eos=mask_eos)
+        finally:
+            self.s.margins, self.s.margins_cap, self.s.own_codes, self.s.forced, self.s.forced_frames = None, 0, None, None, 0
+        n = codes.shape[0]
+        return codes, own[:n].copy(), margins[:n].copy()
+
+
+def set_arith_mode(mode):
+    """0 = include/q3tts_spec.h arithmetic (default), 1 = ggml-CPU generic arithmetic (oracle/q3o_ggml.c)"""
+    lib().q3o_set_arith_mode(1 if mode else 0)
 
 
 class Codec:
