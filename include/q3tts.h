@@ -220,6 +220,26 @@ void q3tts_tf_clear(q3tts_tf* t);
 int q3tts_tf_eval(q3tts_tf* t, const float* x, const int32_t* pos4, int32_t ntok, float* hidden_out, float* logits_out,
                   int32_t row0, int32_t row1);
 
+/* ---- ONNX graph ingestion (host code, no GPU needed) ----
+ * A minimal reader of ONNX ModelProto files (protobuf wire format walked by hand): what `ort::Session` parses for the reference's
+ * qwen3_tts_decoder.onnx / codec_encoder.onnx / speaker_encoder.onnx (/root/reference/src/models/onnx.rs:97-163, 324-347).  It exposes
+ * the node list with attributes, the initialisers (weights, zero-copy into the mapped file), graph inputs / outputs, the op -> HIP
+ * kernel table of this engine, and a check of the streaming-decoder I/O contract (onnx.rs:355-455).  tools/q3onnx_dump prints all of it. */
+typedef struct q3tts_onnx q3tts_onnx;
+int q3tts_onnx_open(const char* path, q3tts_onnx** out);
+void q3tts_onnx_close(q3tts_onnx* m);
+int q3tts_onnx_counts(q3tts_onnx* m, int32_t* n_nodes, int32_t* n_initializers, int32_t* n_inputs, int32_t* n_outputs);
+int64_t q3tts_onnx_summary(q3tts_onnx* m, char* buf, int64_t cap); /* returns the size needed (with NUL) */
+int q3tts_onnx_node(q3tts_onnx* m, int32_t i, const char** op_type, const char** name, int32_t* n_in, int32_t* n_out, int32_t* n_attr);
+const char* q3tts_onnx_node_input(q3tts_onnx* m, int32_t i, int32_t j);
+const char* q3tts_onnx_node_output(q3tts_onnx* m, int32_t i, int32_t j);
+int32_t q3tts_onnx_node_attr_ints(q3tts_onnx* m, int32_t i, const char* attr, int64_t* out, int32_t cap); /* count, -1 = absent */
+int32_t q3tts_onnx_node_attr_float(q3tts_onnx* m, int32_t i, const char* attr, float* out);
+int q3tts_onnx_initializer(q3tts_onnx* m, int32_t i, const char** name, int32_t* dtype, int64_t* dims8, int32_t* ndims, const void** data,
+                           int64_t* nbytes);
+const char* q3tts_onnx_op_kernel(const char* op_type);            /* HIP kernel serving the op, NULL = none yet */
+int q3tts_onnx_decoder_contract(q3tts_onnx* m, char* buf, int64_t cap); /* 0 satisfied, 1 missing (names in buf) */
+
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,
                      const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);

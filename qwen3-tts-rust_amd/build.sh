@@ -9,7 +9,7 @@ FLAGS="${Q3_EXTRA_FLAGS:-} -mllvm -amdgpu-kernarg-preload-count=16 -O3 -std=c++1
 mkdir -p build
 OBJS=""
 PIDS=""
-for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/capi.cpp csrc/capi_ops.cpp csrc/group.cpp csrc/llama_shim.cpp; do
+for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/onnx_reader.cpp csrc/capi.cpp csrc/capi_ops.cpp csrc/group.cpp csrc/llama_shim.cpp; do
   [ -f "$f" ] || continue
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then
@@ -28,4 +28,5 @@ mkdir -p runtime && cp -f libq3tts.so runtime/libllama.so
 # host side: C++ mirror of the reference API + the Boundary-A replay harness (plain g++, no HIP)
 g++ -O2 -std=c++17 -fPIC -ffp-contract=off -shared -o libq3tts_host.so host/tts_engine.cpp -L. -lq3tts -Wl,-rpath,'$ORIGIN'
 g++ -O2 -std=c++17 -ffp-contract=off -o ref_replay host/ref_replay.cpp -ldl
+g++ -O2 -std=c++17 -I../include -o ../tools/q3onnx_dump ../tools/q3onnx_dump.cpp -L. -lq3tts -Wl,-rpath,'$ORIGIN/../qwen3-tts-rust_amd'
 echo "built $(pwd)/libq3tts.so"

@@ -156,3 +156,93 @@ int q3tts_op_project(const float* x, const float* w, const float* b, int32_t n_i
 int q3tts_mel_frames(int32_t n) { const int plen = n + 768; return (plen > 1024 ? plen - 1024 : 0) / 256 + 1; }
 
 } // extern "C"
+
+// ---------------- ONNX graph ingestion (host only, no GPU needed) ----------------
+#include "onnx_reader.h"
+struct q3tts_onnx { std::unique_ptr<OnnxModel> m; std::string text; };
+extern "C" {
+int q3tts_onnx_open(const char* path, q3tts_onnx** out) {
+    Q3_API_BEGIN
+    Q3_CHECK(path && out, "null argument");
+    auto* h = new q3tts_onnx();
+    try { h->m.reset(new OnnxModel(path)); } catch (...) { delete h; throw; }
+    *out = h;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+void q3tts_onnx_close(q3tts_onnx* m) { delete m; }
+int q3tts_onnx_counts(q3tts_onnx* m, int32_t* n_nodes, int32_t* n_init, int32_t* n_in, int32_t* n_out) {
+    if (!m) return Q3TTS_ERR;
+    if (n_nodes) *n_nodes = (int32_t)m->m->nodes.size();
+    if (n_init) *n_init = (int32_t)m->m->initializers.size();
+    if (n_in) *n_in = (int32_t)m->m->inputs.size();
+    if (n_out) *n_out = (int32_t)m->m->outputs.size();
+    return Q3TTS_OK;
+}
+int64_t q3tts_onnx_summary(q3tts_onnx* m, char* buf, int64_t cap) {
+    if (!m) return -1;
+    m->text = m->m->summary();
+    if (buf && cap > 0) { const size_t n = std::min((size_t)cap - 1, m->text.size()); std::memcpy(buf, m->text.data(), n); buf[n] = 0; }
+    return (int64_t)m->text.size() + 1;
+}
+int q3tts_onnx_node(q3tts_onnx* m, int32_t i, const char** op_type, const char** name, int32_t* n_in, int32_t* n_out, int32_t* n_attr) {
+    Q3_API_BEGIN
+    Q3_CHECK(m && i >= 0 && i < (int)m->m->nodes.size(), "node index out of range");
+    const OnnxNode& n = m->m->nodes[i];
+    if (op_type) *op_type = n.op_type.c_str();
+    if (name) *name = n.name.c_str();
+    if (n_in) *n_in = (int32_t)n.inputs.size();
+    if (n_out) *n_out = (int32_t)n.outputs.size();
+    if (n_attr) *n_attr = (int32_t)n.attrs.size();
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+const char* q3tts_onnx_node_input(q3tts_onnx* m, int32_t i, int32_t j) {
+    return (m && i >= 0 && i < (int)m->m->nodes.size() && j >= 0 && j < (int)m->m->nodes[i].inputs.size()) ? m->m->nodes[i].inputs[j].c_str() : nullptr;
+}
+const char* q3tts_onnx_node_output(q3tts_onnx* m, int32_t i, int32_t j) {
+    return (m && i >= 0 && i < (int)m->m->nodes.size() && j >= 0 && j < (int)m->m->nodes[i].outputs.size()) ? m->m->nodes[i].outputs[j].c_str() : nullptr;
+}
+/* INT / INTS attribute -> values (returns the count, -1 when the node has no such attribute) */
+int32_t q3tts_onnx_node_attr_ints(q3tts_onnx* m, int32_t i, const char* attr, int64_t* out, int32_t cap) {
+    if (!m || i < 0 || i >= (int)m->m->nodes.size() || !attr) return -1;
+    const OnnxAttr* a = m->m->nodes[i].attr(attr);
+    if (!a) return -1;
+    if (a->type == 2 || (a->ints.empty() && a->type == 0)) { if (out && cap > 0) out[0] = a->i; return 1; }
+    for (int k = 0; k < (int)a->ints.size() && k < cap; k++) out[k] = a->ints[k];
+    return (int32_t)a->ints.size();
+}
+int32_t q3tts_onnx_node_attr_float(q3tts_onnx* m, int32_t i, const char* attr, float* out) {
+    if (!m || i < 0 || i >= (int)m->m->nodes.size() || !attr || !out) return -1;
+    const OnnxAttr* a = m->m->nodes[i].attr(attr);
+    if (!a) return -1;
+    *out = a->f;
+    return 1;
+}
+int q3tts_onnx_initializer(q3tts_onnx* m, int32_t i, const char** name, int32_t* dtype, int64_t* dims8, int32_t* ndims, const void** data, int64_t* nbytes) {
+    Q3_API_BEGIN
+    Q3_CHECK(m && i >= 0 && i < (int)m->m->initializers.size(), "initializer index out of range");
+    const OnnxTensor& t = m->m->initializers[i];
+    Q3_CHECK(t.dims.size() <= 8, "more than 8 dimensions");
+    if (name) *name = t.name.c_str();
+    if (dtype) *dtype = t.data_type;
+    if (ndims) *ndims = (int32_t)t.dims.size();
+    if (dims8) for (size_t d = 0; d < t.dims.size(); d++) dims8[d] = t.dims[d];
+    const void* p = t.raw; int64_t nb = (int64_t)t.raw_bytes;
+    if (!p && !t.float_data.empty()) { p = t.float_data.data(); nb = (int64_t)t.float_data.size() * 4; }
+    else if (!p && !t.int64_data.empty()) { p = t.int64_data.data(); nb = (int64_t)t.int64_data.size() * 8; }
+    else if (!p && !t.int32_data.empty()) { p = t.int32_data.data(); nb = (int64_t)t.int32_data.size() * 4; }
+    if (data) *data = p;
+    if (nbytes) *nbytes = nb;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+const char* q3tts_onnx_op_kernel(const char* op_type) { return op_type ? onnx_op_kernel(op_type) : nullptr; }
+/* 0: the graph carries the streaming-decoder inputs / outputs of onnx.rs:355-455; 1: something is missing (listed in buf) */
+int q3tts_onnx_decoder_contract(q3tts_onnx* m, char* buf, int64_t cap) {
+    if (!m) return Q3TTS_ERR;
+    const std::string miss = m->m->check_decoder_contract();
+    if (buf && cap > 0) { const size_t n = std::min((size_t)cap - 1, miss.size()); std::memcpy(buf, miss.data(), n); buf[n] = 0; }
+    return miss.empty() ? 0 : 1;
+}
+} // extern "C"

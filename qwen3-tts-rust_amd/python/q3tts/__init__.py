@@ -68,6 +68,8 @@ SYMBOLS = [
     "q3tts_group_submit", "q3tts_group_submit_text", "q3tts_group_device_of", "q3tts_group_poll", "q3tts_group_fetch", "q3tts_group_wait",
     "q3tts_group_release", "q3tts_group_start", "q3tts_group_stop", "q3tts_comm_available", "q3tts_comm_unique_id", "q3tts_comm_create",
     "q3tts_comm_destroy", "q3tts_comm_voice_register", "q3tts_engine_device",
+    "q3tts_onnx_open", "q3tts_onnx_close", "q3tts_onnx_counts", "q3tts_onnx_summary", "q3tts_onnx_node", "q3tts_onnx_node_input", "q3tts_onnx_node_output",
+    "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
 ]
 
 
@@ -537,3 +539,80 @@ def mel(audio):
     out = np.zeros((n, 128), np.float32)
     _chk(lib().q3tts_mel(_p(audio), audio.size, _p(out)))
     return out
+
+
+class OnnxModel:
+    """ONNX ModelProto through the C ABI's reader (q3tts_onnx_*): nodes, attributes, initialisers, I/O contract"""
+
+    def __init__(self, path):
+        L = lib()
+        L.q3tts_onnx_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.q3tts_onnx_close.argtypes = [C.c_void_p]
+        L.q3tts_onnx_counts.argtypes = [C.c_void_p] + [C.POINTER(C.c_int32)] * 4
+        L.q3tts_onnx_summary.restype = C.c_int64
+        L.q3tts_onnx_summary.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.q3tts_onnx_node.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_char_p)] + [C.POINTER(C.c_int32)] * 3
+        L.q3tts_onnx_node_input.restype = C.c_char_p
+        L.q3tts_onnx_node_input.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.q3tts_onnx_node_output.restype = C.c_char_p
+        L.q3tts_onnx_node_output.argtypes = [C.c_void_p, C.c_int32, C.c_int32]
+        L.q3tts_onnx_node_attr_ints.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.c_void_p, C.c_int32]
+        L.q3tts_onnx_node_attr_float.argtypes = [C.c_void_p, C.c_int32, C.c_char_p, C.POINTER(C.c_float)]
+        L.q3tts_onnx_initializer.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int32), C.c_void_p, C.POINTER(C.c_int32),
+                                             C.POINTER(C.c_void_p), C.POINTER(C.c_int64)]
+        L.q3tts_onnx_op_kernel.restype = C.c_char_p
+        L.q3tts_onnx_op_kernel.argtypes = [C.c_char_p]
+        L.q3tts_onnx_decoder_contract.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        h = C.c_void_p()
+        _chk(L.q3tts_onnx_open(path.encode(), C.byref(h)))
+        self.h = h.value
+        c = [C.c_int32() for _ in range(4)]
+        L.q3tts_onnx_counts(self.h, *[C.byref(x) for x in c])
+        self.n_nodes, self.n_initializers, self.n_inputs, self.n_outputs = [x.value for x in c]
+
+    def close(self):
+        if self.h:
+            lib().q3tts_onnx_close(self.h)
+        self.h = None
+
+    def summary(self):
+        n = lib().q3tts_onnx_summary(self.h, None, 0)
+        buf = C.create_string_buffer(n)
+        lib().q3tts_onnx_summary(self.h, buf, n)
+        return buf.value.decode()
+
+    def node(self, i):
+        op, nm = C.c_char_p(), C.c_char_p()
+        c = [C.c_int32() for _ in range(3)]
+        _chk(lib().q3tts_onnx_node(self.h, i, C.byref(op), C.byref(nm), *[C.byref(x) for x in c]))
+        return {"op_type": op.value.decode(), "name": nm.value.decode(),
+                "inputs": [lib().q3tts_onnx_node_input(self.h, i, j).decode() for j in range(c[0].value)],
+                "outputs": [lib().q3tts_onnx_node_output(self.h, i, j).decode() for j in range(c[1].value)], "n_attr": c[2].value}
+
+    def attr_ints(self, i, name):
+        buf = (C.c_int64 * 16)()
+        n = lib().q3tts_onnx_node_attr_ints(self.h, i, name.encode(), buf, 16)
+        return None if n < 0 else [buf[k] for k in range(min(n, 16))]
+
+    def attr_float(self, i, name):
+        f = C.c_float()
+        return f.value if lib().q3tts_onnx_node_attr_float(self.h, i, name.encode(), C.byref(f)) == 1 else None
+
+    def initializer(self, i):
+        nm, dt, nd, data, nb = C.c_char_p(), C.c_int32(), C.c_int32(), C.c_void_p(), C.c_int64()
+        dims = (C.c_int64 * 8)()
+        _chk(lib().q3tts_onnx_initializer(self.h, i, C.byref(nm), C.byref(dt), dims, C.byref(nd), C.byref(data), C.byref(nb)))
+        raw = C.string_at(data.value, nb.value) if data.value and nb.value else b""
+        return {"name": nm.value.decode(), "dtype": dt.value, "dims": [dims[k] for k in range(nd.value)], "raw": raw}
+
+    def decoder_contract(self):
+        buf = C.create_string_buffer(4096)
+        rc = lib().q3tts_onnx_decoder_contract(self.h, buf, 4096)
+        return rc == 0, buf.value.decode()
+
+
+def onnx_op_kernel(op_type):
+    lib().q3tts_onnx_op_kernel.restype = C.c_char_p
+    lib().q3tts_onnx_op_kernel.argtypes = [C.c_char_p]
+    r = lib().q3tts_onnx_op_kernel(op_type.encode())
+    return r.decode() if r else None
