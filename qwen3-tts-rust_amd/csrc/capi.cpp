@@ -91,6 +91,7 @@ int q3tts_poll(q3tts_engine* e, int64_t id, q3tts_req_status* o) {
     const ReqStatus s = e->e->poll(id);
     o->state = s.state; o->n_frames = s.n_frames; o->n_pcm = s.n_pcm; o->queue_ms = s.queue_ms; o->prefill_ms = s.prefill_ms;
     o->first_chunk_ms = s.first_chunk_ms; o->total_ms = s.total_ms;
+    if (s.state == REQ_FAILED) set_last_error(s.error.empty() ? "request failed" : s.error); // state says it failed; q3tts_last_error() says why
     return Q3TTS_OK;
     Q3_API_END(Q3TTS_ERR)
 }

@@ -780,6 +780,7 @@ ReqStatus Engine::poll(int64_t id) {
     s.queue_ms = r.t_admit > 0 ? r.t_admit - r.t_submit : now_ms() - r.t_submit;
     s.prefill_ms = r.prefill_ms; s.first_chunk_ms = r.first_chunk_ms;
     s.total_ms = (r.state == REQ_DONE ? r.t_done : now_ms()) - r.t_submit;
+    s.error = r.error;
     return s;
 }
 

@@ -60,6 +60,7 @@ enum ReqState { REQ_QUEUED = 0, REQ_RUNNING = 1, REQ_DRAINING = 2, REQ_DONE = 3,
 struct ReqStatus {
     int state = REQ_QUEUED; int n_frames = 0; int64_t n_pcm = 0; // frames emitted / PCM samples decoded so far
     double queue_ms = 0, prefill_ms = 0, first_chunk_ms = 0, total_ms = 0;
+    std::string error; // REQ_FAILED: what the scheduler / decoder thread reported
 };
 
 struct Voice { // a registered voice: preset embedding or clone material (engine.rs:390-435, voice_file.rs:5-22)

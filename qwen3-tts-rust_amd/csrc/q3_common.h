@@ -21,7 +21,8 @@ struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
 #define Q3_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     throw ::q3::Error(std::string(#expr) + ": " + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); } } while (0)
 // launch-configuration failures (bad grid, LDS opt-in missing on this device, ...) are reported by hipGetLastError only
-#define Q3_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) { \
+// (hipErrorNotReady is what a polling hipEventQuery / hipStreamQuery leaves behind on this thread: not a launch failure)
+#define Q3_LAUNCH_CHECK() do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess && e_ != hipErrorNotReady) { \
     throw ::q3::Error(std::string("kernel launch failed: ") + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); } } while (0)
 #define Q3_CHECK(cond, msg) do { if (!(cond)) throw ::q3::Error(std::string(msg) + " (" #cond ") at " __FILE__ ":" + std::to_string(__LINE__)); } while (0)
 

@@ -48,7 +48,7 @@ int main(int argc, char** argv) {
         if (q3tts_group_wait(g, ids[i], 120000.0) != 0) { fprintf(stderr, "wait: %s\n", q3tts_last_error()); return 1; }
         q3tts_req_status st;
         CHECK(q3tts_group_poll(g, ids[i], &st));
-        if (st.state != Q3TTS_REQ_DONE || st.n_frames != 6) { fprintf(stderr, "request %d state %d frames %d\n", i, st.state, st.n_frames); return 1; }
+        if (st.state != Q3TTS_REQ_DONE || st.n_frames != 6) { fprintf(stderr, "request %d state %d frames %d: %s\n", i, st.state, st.n_frames, q3tts_last_error()); return 1; }
         codes[i].resize(6 * 16);
         std::vector<float> pcm((size_t)st.n_pcm);
         int32_t gf = 0; int64_t gp = 0;
