@@ -286,8 +286,14 @@ Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {
     }
     FrameGraph& fg = *slot;
     if (capture && !fg.exec) {
+        // one capture at a time per process: engines of a multi-device group (or several engines on one device) capture their frame graphs
+        // from different threads, and concurrent thread-local captures were seen to invalidate each other on ROCm 7.2
+        static std::mutex capture_mu;
+        std::lock_guard<std::mutex> lk(capture_mu);
+        (void)hipGetLastError();
         Q3_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
-        record_frame(fg, sampled);
+        try { record_frame(fg, sampled); }
+        catch (...) { hipGraph_t dead = nullptr; (void)hipStreamEndCapture(st_, &dead); if (dead) (void)hipGraphDestroy(dead); throw; }
         Q3_HIP(hipStreamEndCapture(st_, &fg.graph));
         Q3_HIP(hipGraphInstantiate(&fg.exec, fg.graph, nullptr, nullptr, 0));
     }

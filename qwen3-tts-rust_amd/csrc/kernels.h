@@ -95,6 +95,8 @@ void launch_argmax_keys(hipStream_t st, const float* logits, int stride, int n, 
 
 
 void launch_copy_f32(hipStream_t st, const float* src, float* dst, size_t n);
+// per-device kernel attribute opt-ins (dynamic LDS above 64 KiB); call once per device outside any stream capture
+void init_kernel_attributes();
 
 // ---- 16/32-bit float weights (bf16 / f16 / f32 files): f32 activations, no activation quantisation (spec S3 float form:
 // 8-element fma sub-chains, block = (c0+c1)+(c2+c3), blocks added in order inside a segment, segments / super-segments in order)

@@ -115,6 +115,26 @@ static int mfma2_ztiles(int rowgroups, int nsseg, int ntok) {
     int z = (target + rowgroups * nsseg - 1) / (rowgroups * nsseg);
     return z < 1 ? 1 : (z > ntiles ? ntiles : z);
 }
+__global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                              float* __restrict__ out, int out_stride, int ntok);
+template <int TYPE>
+__global__ void k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x, int x_stride, float* __restrict__ out,
+                                  int out_stride, int ntok);
+void init_fused_kernel_attributes();
+// dynamic-LDS opt-ins (per device): done once at engine construction so that no attribute call happens inside a stream capture
+void init_kernel_attributes() {
+    static bool done[64] = {};
+    int dev = 0;
+    Q3_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev > 63 || done[dev]) return;
+    Q3_HIP(hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
+    constexpr int lds = Q3_SSEG_SEGS * 64 * 33 * (int)sizeof(float); // k_gemm_float_mfma: [8 segments][64 rows][FM_PAD]
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    init_fused_kernel_attributes();
+    done[dev] = true;
+}
 static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
@@ -283,10 +303,7 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (ntok > 8 && !lpr_hint) {
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const size_t lds = 16 * 2048 + 16 * 128 + 8 * 16 * 64 * 4; // 66 KiB: activations of 16 tokens + segment sums
-        static bool attr_set[64] = {}; // the opt-in is per device
-        int dev = 0;
-        Q3_HIP(hipGetDevice(&dev));
-        if (dev >= 0 && dev < 64 && !attr_set[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); attr_set[dev] = true; }
+        init_kernel_attributes(); // (normally done at engine construction; a no-op then)
         hipLaunchKernelGGL(k_gemm_q8_tok, dim3((nrows + 63) / 64, nsseg, (ntok + 15) / 16), dim3(64 * nw), lds, st, w, row0, nrows, xq, xd, out,
                            out_stride, ntok);
         return;
@@ -1617,10 +1634,7 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
     static const int min_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_MIN"); return e ? atoi(e) : 2; }();
     if (!w.wt || min_tok <= 0 || ntok < min_tok || row0 % 64 != 0 || (w.K & 255) != 0 || (x_stride & 3) != 0 || ((uintptr_t)x & 15) != 0) return false;
     constexpr size_t lds = (size_t)Q3_SSEG_SEGS * 64 * FM_PAD * sizeof(float);
-    static bool attr_set[64] = {}; // the opt-in is per device
-    int dev = 0;
-    Q3_HIP(hipGetDevice(&dev));
-    if (dev >= 0 && dev < 64 && !attr_set[dev]) { Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<TYPE>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr_set[dev] = true; }
+    init_kernel_attributes(); // (normally done at engine construction; a no-op then)
     static const int wide_tok = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WIDE"); return e ? atoi(e) : 96; }();
     if (ntok < wide_tok) { // few tokens: 16 x 16 tiles, 16x more workgroups
         dim3 grid16(xcd_grid((nrows + 15) / 16, (ntok + 15) / 16));

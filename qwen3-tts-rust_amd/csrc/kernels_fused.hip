@@ -975,9 +975,18 @@ __global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x,
     for (int i = 0; i < n_in; i++) { const float t = xs[i * 16 + tl] * wp[(size_t)i * 16]; sum = sum + t; }
     if (t0 + tl < ntok) out[(size_t)(t0 + tl) * out_stride + o] = sum;
 }
+static bool g_attr_set[64] = {}, g_attr_mt[64] = {}; // the dynamic-LDS opt-in is per device
+// called once per device at engine construction, so that no attribute call happens inside a stream capture
+void init_fused_kernel_attributes() {
+    int dev = 0;
+    Q3_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev > 63) return;
+    if (!g_attr_mt[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); g_attr_mt[dev] = true; }
+    if (!g_attr_set[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); g_attr_set[dev] = true; }
+}
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
                         float* out, int out_stride, int ntok) {
-    static bool attr_set[64] = {}, attr_mt[64] = {}; // the dynamic-LDS opt-in is per device
+    bool* attr_set = g_attr_set; bool* attr_mt = g_attr_mt;
     int dev = 0;
     (void)hipGetDevice(&dev);
     dev = dev < 0 || dev > 63 ? 0 : dev;

@@ -175,7 +175,7 @@ float* Transformer::load_f32(const Gguf& g, const std::string& name, int64_t n_e
 }
 
 Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ctx_(n_ctx), max_tok_(max_tok) {
-
+    init_kernel_attributes();
     if (const char* e = std::getenv("Q3_UNFUSED")) fused = !(e[0] == '1'); // A/B switch for the parity tests (9 launches/layer)
     Gguf g(path);
     hp_.arch = g.kv_str("general.architecture", "qwen3");
