@@ -268,8 +268,15 @@ void Engine::record_frame(FrameGraph& fg, bool sampled) {
     Q3_LAUNCH_CHECK();
 }
 
+std::mutex& capture_mutex() { static std::mutex mu; return mu; }
+
 Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {
     std::unique_ptr<FrameGraph>& slot = graphs_[width * 2 + (sampled ? 1 : 0)];
+    // one graph construction at a time per process: engines of a multi-device group (or several engines on one device) build their frame
+    // graphs from different threads; the synchronous allocations / uploads below and concurrent thread-local captures were seen to
+    // invalidate another thread's capture on ROCm 7.2 ("operation failed due to a previous error during capture")
+    std::unique_lock<std::mutex> build_lock(capture_mutex(), std::defer_lock);
+    if (!slot || (capture && !slot->exec)) build_lock.lock();
     if (!slot) {
         slot.reset(new FrameGraph());
         FrameGraph& fg = *slot;
@@ -286,10 +293,6 @@ Engine::FrameGraph& Engine::frame_graph(int width, bool sampled, bool capture) {
     }
     FrameGraph& fg = *slot;
     if (capture && !fg.exec) {
-        // one capture at a time per process: engines of a multi-device group (or several engines on one device) capture their frame graphs
-        // from different threads, and concurrent thread-local captures were seen to invalidate each other on ROCm 7.2
-        static std::mutex capture_mu;
-        std::lock_guard<std::mutex> lk(capture_mu);
         (void)hipGetLastError();
         Q3_HIP(hipStreamBeginCapture(st_, hipStreamCaptureModeThreadLocal));
         try { record_frame(fg, sampled); }

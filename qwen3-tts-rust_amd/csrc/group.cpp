@@ -198,7 +198,7 @@ int q3tts_group_voice_register(q3tts_group* g, const float* spk, const int32_t* 
     std::lock_guard<std::mutex> lk(g->mu);
     const std::vector<uint8_t> pay = pack_voice(spk, ref_codes, n_ref_codes, ref_text, n_ref_text);
     const int n = (int)g->eng.size();
-    for (auto& s : g->slot) s.ensure(pay.size());
+    { std::lock_guard<std::mutex> cap(capture_mutex()); for (auto& s : g->slot) s.ensure(pay.size()); } // allocations never overlap a running engine's capture
     // the owner (first device) uploads once ...
     DevSlot& s0 = g->slot[0];
     Q3_HIP(hipSetDevice(s0.dev));
@@ -336,7 +336,7 @@ int q3tts_comm_voice_register(q3tts_comm* c, q3tts_engine* e, int32_t root, cons
     std::vector<uint8_t> pay;
     if (c->rank == root) pay = pack_voice(spk, ref_codes, n_ref_codes, ref_text, n_ref_text);
     // 1) the 32-byte header (sizes are known at the root only), 2) the payload
-    s.ensure(kHdrBytes);
+    { std::lock_guard<std::mutex> cap(capture_mutex()); s.ensure(kHdrBytes); }
     if (c->rank == root) { std::memcpy(s.h_buf, pay.data(), kHdrBytes); Q3_HIP(hipMemcpyAsync(s.d_buf, s.h_buf, kHdrBytes, hipMemcpyHostToDevice, s.st)); }
     nccl_check(rccl().Broadcast(s.d_buf, s.d_buf, kHdrBytes, kNcclChar, root, c->comm, s.st), "ncclBroadcast(header)");
     Q3_HIP(hipMemcpyAsync(s.h_buf, s.d_buf, kHdrBytes, hipMemcpyDeviceToHost, s.st));
@@ -344,7 +344,7 @@ int q3tts_comm_voice_register(q3tts_comm* c, q3tts_engine* e, int32_t root, cons
     int64_t hdr[4];
     std::memcpy(hdr, s.h_buf, kHdrBytes);
     const size_t total = kHdrBytes + payload_bytes(hdr);
-    s.ensure(total);
+    { std::lock_guard<std::mutex> cap(capture_mutex()); s.ensure(total); }
     if (c->rank == root) { std::memcpy(s.h_buf, pay.data(), total); Q3_HIP(hipMemcpyAsync(s.d_buf, s.h_buf, total, hipMemcpyHostToDevice, s.st)); }
     nccl_check(rccl().Broadcast(s.d_buf, s.d_buf, total, kNcclChar, root, c->comm, s.st), "ncclBroadcast(voice)");
     if (c->rank != root) std::memset(s.h_buf, 0, total);
