@@ -220,6 +220,17 @@ void q3tts_tf_clear(q3tts_tf* t);
 int q3tts_tf_eval(q3tts_tf* t, const float* x, const int32_t* pos4, int32_t ntok, float* hidden_out, float* logits_out,
                   int32_t row0, int32_t row1);
 
+/* ---- tokenizer (host code) ----
+ * Byte-level BPE over a HuggingFace tokenizer.json: what the reference's Tokenizer::{load, encode, decode} get from the `tokenizers` crate
+ * (/root/reference/src/utils/tokenizer.rs:9-38): <model_dir>/tokenizer/tokenizer.json, encode(text, add_special_tokens = false),
+ * decode(ids, skip_special_tokens = false).  Qwen2-family files: added tokens, Split(Qwen2 pattern) + ByteLevel, BPE merges. */
+typedef struct q3tts_tokenizer q3tts_tokenizer;
+int q3tts_tokenizer_open(const char* tokenizer_json, q3tts_tokenizer** out);
+void q3tts_tokenizer_close(q3tts_tokenizer* t);
+int32_t q3tts_tokenizer_encode(q3tts_tokenizer* t, const char* text_utf8, int32_t* ids, int32_t cap); /* count (may exceed cap), < 0 error */
+int64_t q3tts_tokenizer_decode(q3tts_tokenizer* t, const int32_t* ids, int32_t n, char* buf, int64_t cap); /* byte length, < 0 error */
+int32_t q3tts_tokenizer_vocab_size(q3tts_tokenizer* t);
+
 /* ---- ONNX graph ingestion (host code, no GPU needed) ----
  * A minimal reader of ONNX ModelProto files (protobuf wire format walked by hand): what `ort::Session` parses for the reference's
  * qwen3_tts_decoder.onnx / codec_encoder.onnx / speaker_encoder.onnx (/root/reference/src/models/onnx.rs:97-163, 324-347).  It exposes

@@ -246,3 +246,38 @@ int q3tts_onnx_decoder_contract(q3tts_onnx* m, char* buf, int64_t cap) {
     return miss.empty() ? 0 : 1;
 }
 } // extern "C"
+
+// ---------------- tokenizer (host only) ----------------
+#include "tokenizer.h"
+struct q3tts_tokenizer { std::unique_ptr<Tokenizer> t; std::string text; };
+extern "C" {
+int q3tts_tokenizer_open(const char* tokenizer_json, q3tts_tokenizer** out) {
+    Q3_API_BEGIN
+    Q3_CHECK(tokenizer_json && out, "null argument");
+    auto* h = new q3tts_tokenizer();
+    try { h->t.reset(new Tokenizer(tokenizer_json)); } catch (...) { delete h; throw; }
+    *out = h;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+void q3tts_tokenizer_close(q3tts_tokenizer* t) { delete t; }
+/* returns the number of ids (which may exceed cap: call again with a larger buffer), < 0 on error */
+int32_t q3tts_tokenizer_encode(q3tts_tokenizer* t, const char* text_utf8, int32_t* ids, int32_t cap) {
+    Q3_API_BEGIN
+    Q3_CHECK(t && text_utf8, "null argument");
+    const std::vector<int32_t> v = t->t->encode(text_utf8);
+    for (size_t i = 0; i < v.size() && (int32_t)i < cap; i++) ids[i] = v[i];
+    return (int32_t)v.size();
+    Q3_API_END(-1)
+}
+/* returns the byte length of the decoded UTF-8 text (without NUL; may exceed cap - 1), < 0 on error */
+int64_t q3tts_tokenizer_decode(q3tts_tokenizer* t, const int32_t* ids, int32_t n, char* buf, int64_t cap) {
+    Q3_API_BEGIN
+    Q3_CHECK(t && (ids || n == 0) && n >= 0, "bad arguments");
+    t->text = t->t->decode(std::vector<int32_t>(ids, ids + n));
+    if (buf && cap > 0) { const size_t k = std::min((size_t)cap - 1, t->text.size()); std::memcpy(buf, t->text.data(), k); buf[k] = 0; }
+    return (int64_t)t->text.size();
+    Q3_API_END(-1)
+}
+int32_t q3tts_tokenizer_vocab_size(q3tts_tokenizer* t) { return t ? t->t->vocab_size() : 0; }
+} // extern "C"

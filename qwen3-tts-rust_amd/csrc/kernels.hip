@@ -101,12 +101,12 @@ k_gemm_q8_wave(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
 static int wave_form_min();
 // Which form serves a launch.  Measured on MI355X (scripts/ubench_gemm.hip, profiles/r02_ubench_gemm.txt): at 64 tokens the first form (two
 // workgroups per CU, phases of different workgroups overlap) and the second (one pass, no conversions, 2 waves per SIMD) tie per launch
-// (talker gate/up 17.6 vs 18.0 us) and the first wins the 64-slot step (7.46 vs 7.79 ms); from 128 tokens the second form's single pass
-// over the activations is ahead.  The wave-per-tile form needs >= ~1500 waves and is bound by activation re-reads through L2 (as many
-// activation bytes as weight bytes per tile); it is opt-in (Q3_GEMM_WAVE_MIN).  Q3_GEMM_V1=1 / Q3_GEMM_V2=1 force one form everywhere.
+// (talker gate/up 17.6 vs 18.0 us) and the first wins the 64-slot step (7.43 vs 7.74 ms, 618 vs 593 audio-s/s) and the 256-slot run (920 vs
+// 846 audio-s/s), so the first form serves every launch and the second is opt-in (Q3_GEMM_V2=1).  The wave-per-tile form needs >= ~1500
+// waves and is bound by activation re-reads through L2 (as many activation bytes as weight bytes per tile); opt-in too (Q3_GEMM_WAVE_MIN).
 static bool gemm_v1(int ntok) {
     static const int mode = [] { const char* a = std::getenv("Q3_GEMM_V1"); const char* b = std::getenv("Q3_GEMM_V2"); return (a && a[0] == '1') ? 1 : (b && b[0] == '1') ? 2 : 0; }();
-    return mode == 1 || (mode == 0 && ntok < 128);
+    return mode != 2;
 }
 // token tiles per launch dimension z of the second form: one workgroup (8 waves) per CU at 2 waves per SIMD, so aim at >= 2 workgroups per CU
 static int mfma2_ztiles(int rowgroups, int nsseg, int ntok) {

@@ -6,6 +6,7 @@
 #include <cstring>
 #include <dirent.h>
 #include <fstream>
+#include <memory>
 #include <sstream>
 #include <stdexcept>
 
@@ -208,6 +209,22 @@ TtsEngine TtsEngine::new_(const std::string& model_dir, const std::string& quant
     p.model_dir = model_dir.c_str(); p.quant = quant.c_str(); p.max_batch = 1;
     if (q3tts_engine_create(&p, &t.e_) != Q3TTS_OK) throw std::runtime_error(std::string("Failed to load TtsEngine: ") + q3tts_last_error());
     t.tok_ = std::move(tok);
+    if (!t.tok_) { // engine.rs:103-104 / utils/tokenizer.rs:9-15: <model_dir>/tokenizer/tokenizer.json through the engine's own BPE reader (row f-3)
+        const std::string tj = model_dir + "/tokenizer/tokenizer.json";
+        if (FILE* f = fopen(tj.c_str(), "rb")) {
+            fclose(f);
+            q3tts_tokenizer* th = nullptr;
+            if (q3tts_tokenizer_open(tj.c_str(), &th) != Q3TTS_OK) { q3tts_engine_destroy(t.e_); t.e_ = nullptr; throw std::runtime_error(std::string("Failed to load tokenizer: ") + q3tts_last_error()); }
+            std::shared_ptr<q3tts_tokenizer> sp(th, [](q3tts_tokenizer* p) { q3tts_tokenizer_close(p); });
+            t.tok_ = [sp](const std::string& text) {
+                std::vector<int32_t> ids(2 * text.size() + 16);
+                const int32_t n = q3tts_tokenizer_encode(sp.get(), text.c_str(), ids.data(), (int32_t)ids.size());
+                if (n < 0) throw std::runtime_error(std::string("Error encoding text: ") + q3tts_last_error());
+                ids.resize((size_t)n);
+                return ids;
+            };
+        }
+    }
     // engine.rs:156-166: <model_dir>/preset_speakers, else ./speakers
     for (const std::string& d : {model_dir + "/preset_speakers", std::string("speakers")}) {
         if (DIR* dd = opendir(d.c_str())) { closedir(dd); t.load_speakers(d); break; }

@@ -6,12 +6,14 @@
 //   AudioSample              /root/reference/src/utils/audio.rs:4-46       (save_wav: i16, x32767 clamp)
 //   TtsEngine::{new_, set_max_steps, set_sampler_config, get_sampler_config, load_speakers, get_speaker,
 //               generate_with_voice, create_voice_file}   /root/reference/src/tts/engine.rs:84-435
-// Text -> token ids (HF tokenizers crate, src/utils/tokenizer.rs) is SURVEY row f-3 and stays pluggable.
+// Text -> token ids (src/utils/tokenizer.rs): <model_dir>/tokenizer/tokenizer.json is read by the engine's own byte-level BPE (q3tts_tokenizer_*,
+// SURVEY row f-3) when the file exists; a caller-supplied tokenizer function takes precedence.
 #pragma once
 #include "../../include/q3tts.h"
 #include <functional>
 #include <map>
 #include <optional>
+#include <stdexcept>
 #include <string>
 #include <vector>
 
@@ -56,6 +58,8 @@ public:
     const SamplerConfig& get_sampler_config() const { return sampler_; }           // :182-184
     void load_speakers(const std::string& dir);                                    // :187-208
     const VoiceFile& get_speaker(const std::string& id_or_name) const;             // :211-231 (vivian fallback)
+    bool has_tokenizer() const { return (bool)tok_; }
+    std::vector<int32_t> encode(const std::string& text) const { if (!tok_) throw std::runtime_error("Failed to load tokenizer: no tokenizer/tokenizer.json in the model directory"); return tok_(text); }
     // generate_with_voice -- :390-435; text goes through the pluggable tokenizer
     AudioSample generate_with_voice(const std::string& text, const VoiceFile& voice, const std::optional<std::string>& instruct = std::nullopt);
     AudioSample generate_with_voice_ids(const std::vector<int32_t>& text_ids, const VoiceFile& voice,

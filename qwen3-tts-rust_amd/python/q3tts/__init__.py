@@ -70,6 +70,7 @@ SYMBOLS = [
     "q3tts_comm_destroy", "q3tts_comm_voice_register", "q3tts_engine_device",
     "q3tts_onnx_open", "q3tts_onnx_close", "q3tts_onnx_counts", "q3tts_onnx_summary", "q3tts_onnx_node", "q3tts_onnx_node_input", "q3tts_onnx_node_output",
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
+    "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
 
 
@@ -616,3 +617,40 @@ def onnx_op_kernel(op_type):
     lib().q3tts_onnx_op_kernel.argtypes = [C.c_char_p]
     r = lib().q3tts_onnx_op_kernel(op_type.encode())
     return r.decode() if r else None
+
+
+class Tokenizer:  # utils/tokenizer.rs:4-38
+    def __init__(self, tokenizer_json):
+        L = lib()
+        L.q3tts_tokenizer_open.argtypes = [C.c_char_p, C.POINTER(C.c_void_p)]
+        L.q3tts_tokenizer_close.argtypes = [C.c_void_p]
+        L.q3tts_tokenizer_encode.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int32]
+        L.q3tts_tokenizer_decode.restype = C.c_int64
+        L.q3tts_tokenizer_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_char_p, C.c_int64]
+        L.q3tts_tokenizer_vocab_size.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        _chk(L.q3tts_tokenizer_open(tokenizer_json.encode(), C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            lib().q3tts_tokenizer_close(self.h)
+        self.h = None
+
+    def encode(self, text):
+        raw = text.encode("utf-8")
+        cap = max(16, 2 * len(raw) + 8)
+        ids = np.zeros(cap, np.int32)
+        n = lib().q3tts_tokenizer_encode(self.h, raw, _p(ids), cap)
+        if n < 0:
+            raise Q3Error(lib().q3tts_last_error().decode())
+        return ids[:n].tolist()
+
+    def decode(self, ids):
+        a = np.ascontiguousarray(ids, np.int32)
+        n = lib().q3tts_tokenizer_decode(self.h, _p(a), a.size, None, 0)
+        if n < 0:
+            raise Q3Error(lib().q3tts_last_error().decode())
+        buf = C.create_string_buffer(n + 1)
+        lib().q3tts_tokenizer_decode(self.h, _p(a), a.size, buf, n + 1)
+        return buf.raw[:n].decode("utf-8", errors="replace")

@@ -40,6 +40,20 @@ int main(int argc, char** argv) {
         catch (const std::runtime_error& e) { if (std::string(e.what()).find("AudioEncoder not loaded (required for processing raw audio)") == std::string::npos) throw; }
         try { eng.create_voice_file("x.wav", "hello"); throw std::runtime_error("create_voice_file should fail"); }
         catch (const std::runtime_error& e) { if (std::string(e.what()).find("AudioEncoder not loaded") == std::string::npos) throw; }
+        if (eng.has_tokenizer()) { // text in -> audio out (engine.rs:390-435 with utils/tokenizer.rs): the text path must equal the ids path
+            const std::string text = "Hello, it's 42 degrees!";
+            const std::vector<int32_t> tids = eng.encode(text);
+            sc.temperature = 0.0f; eng.set_sampler_config(sc);
+            std::vector<int32_t> ca, cb;
+            AudioSample ta = eng.generate_with_voice(text, v);
+            AudioSample tb = eng.generate_with_voice_ids(tids, v, nullptr, nullptr, &cb);
+            if (ta.samples != tb.samples || tids.empty()) throw std::runtime_error("text path differs from the ids path");
+            printf("TEXTIDS");
+            for (int32_t x : tids) printf(" %d", x);
+            printf("\nTEXTCODES");
+            for (int32_t x : cb) printf(" %d", x);
+            printf("\n");
+        }
         printf("PRESET");
         for (int32_t x : codes) printf(" %d", x);
         printf("\nCLONE");

@@ -432,9 +432,23 @@ def test_cpp_host_mirror_matches_ctypes_path(gpu, tiny_model, vivian, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host", "host_mirror_main.cpp"),
                            "-L" + pkg, "-lq3tts_host", "-lq3tts", "-Wl,-rpath," + pkg])
     wav = str(tmp_path / "out.wav")
+    # text in -> audio out: a tokenizer.json (written with the Python `tokenizers` package, Qwen2 pattern) in <model_dir>/tokenizer/ is picked up
+    # by TtsEngine::new (engine.rs:103-104); token ids < the tiny model's text-table rows fall back deterministically otherwise
+    tok_ids = None
+    try:
+        import test_tokenizer_cpu as TT
+        tdir = os.path.join(tiny_model, "tokenizer")
+        os.makedirs(tdir, exist_ok=True)
+        tok, tpath = TT._build(tmp_path, vocab_size=500)
+        os.replace(tpath, os.path.join(tdir, "tokenizer.json"))
+        tok_ids = tok.encode("Hello, it's 42 degrees!", add_special_tokens=False).ids
+    except ImportError:
+        pass
     r = subprocess.run([exe, tiny_model, os.path.join(ROOT, "tests", "golden", "speakers"), wav], capture_output=True, text=True, cwd=str(tmp_path))
     assert r.returncode == 0 and r.stdout.strip().endswith("OK"), r.stderr[-2000:]
     lines = {l.split()[0]: l.split()[1:] for l in r.stdout.strip().splitlines()}
+    if tok_ids is not None:
+        assert [int(x) for x in lines["TEXTIDS"]] == tok_ids and len(lines["TEXTCODES"]) % 16 == 0 and len(lines["TEXTCODES"]) > 0
     ge = gpu.Engine(tiny_model, "q8_0", max_batch=1, max_steps=16, load_codec=True)
     ids = np.arange(100, 108, dtype=np.int32)
     ref = ge.generate_batch([ge.assets.build_core(ids, lang_id=2055, spk_emb=vivian)], max_steps=10, temperature=0.0, seed=42, mask_eos=False, want_pcm=True)[0]
