@@ -92,7 +92,7 @@ Engine::Engine(const EngineParams& p) : p_(p) {
         async_pf_ = B > 1 && !(e && e[0] == '0');
     }
     if (async_pf_) {
-        talker_pf_.reset(new Transformer(dir + "/qwen3_tts_talker.gguf", Q3_TALKER_NCTX, 256));
+        talker_pf_.reset(new Transformer(*talker_, 256)); // shares the talker's device weights; own activation workspace
         Q3_HIP(hipStreamCreateWithFlags(&st_pf_, hipStreamNonBlocking));
         Q3_HIP(hipEventCreate(&pf_done_)); Q3_HIP(hipEventCreate(&pf_e0_));
         arena_pf_cap_ = (size_t)4096 * (Q3_EMBD * 4 + 24) + ((size_t)1 << 16); // prompts of one admission: at most 4096 rows + routing tables

@@ -252,8 +252,20 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     rope_cos_.alloc(c.size()); rope_cos_.upload(c.data(), c.size());
     rope_sin_.alloc(s.size()); rope_sin_.upload(s.data(), s.size());
     d_mrope_.alloc(4); d_mrope_.upload(hp_.mrope_sec, 4);
+    alloc_workspace();
+}
+
+// second context over the same weights: see transformer.h
+Transformer::Transformer(const Transformer& o, int max_tok)
+    : fused(o.fused), float_mode_(o.float_mode_), foutput_(o.foutput_), hp_(o.hp_), n_ctx_(o.n_ctx_), max_tok_(max_tok), layers_(o.layers_), output_(o.output_),
+      output_norm_(o.output_norm_), ws_(o.ws_), weight_bytes_(o.weight_bytes_), layer_weight_bytes_(o.layer_weight_bytes_), all_q8_(o.all_q8_) {
+    alloc_workspace();
+}
+
+void Transformer::alloc_workspace() {
+    const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
     nparts_d_ = ((ff >> 8) + 7) / 8;
-    const size_t T = (size_t)max_tok;
+    const size_t T = (size_t)max_tok_;
     scratch_.alloc(T * 32); hid_.alloc(T * d); big_logits_.alloc(T * 2176);
     if (float_mode_) { xnf_.alloc(T * d); attf_.alloc(T * dq); actf_.alloc(T * ff); }
     h_.alloc(T * d); h2_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);

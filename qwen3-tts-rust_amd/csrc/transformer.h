@@ -19,6 +19,9 @@ struct TfHparams {
 class Transformer {
 public:
     Transformer(const std::string& gguf_path, int n_ctx, int max_tok);
+    // A second execution context over the SAME device weights (read-only: repacked matrices, norms, RoPE tables are shared through a
+    // reference-counted store); only the activation workspace is new.  Used for the asynchronous prefill lane: no second 1.5 GB copy.
+    Transformer(const Transformer& weights_of, int max_tok);
     const TfHparams& hp() const { return hp_; }
     int n_ctx() const { return n_ctx_; }
     int max_tok() const { return max_tok_; }
@@ -74,14 +77,21 @@ private:
     std::vector<Layer> layers_;
     Q8Mat output_;
     float* output_norm_ = nullptr;
-    std::vector<DevBuf<uint8_t>> blobs_;
+    struct WeightStore { // device memory shared by every context of one model
+        std::vector<DevBuf<uint8_t>> blobs; DevBuf<float> rope_cos, rope_sin; DevBuf<int32_t> d_mrope;
+        std::map<const uint8_t*, uint8_t*> mat_meta, mat_types;
+    };
+    std::shared_ptr<WeightStore> ws_;
+    std::vector<DevBuf<uint8_t>>& blobs_ = ws_init()->blobs;
     size_t weight_bytes_ = 0, layer_weight_bytes_ = 0;
-    DevBuf<float> rope_cos_, rope_sin_;
-    DevBuf<int32_t> d_mrope_;
+    DevBuf<float>& rope_cos_ = ws_->rope_cos; DevBuf<float>& rope_sin_ = ws_->rope_sin;
+    DevBuf<int32_t>& d_mrope_ = ws_->d_mrope;
+    WeightStore* ws_init() { if (!ws_) ws_ = std::make_shared<WeightStore>(); return ws_.get(); }
+    void alloc_workspace();
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
     bool same_seq_ = false; bool short_ctx_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
-    std::map<const uint8_t*, uint8_t*> mat_meta_, mat_types_;
+    std::map<const uint8_t*, uint8_t*>& mat_meta_ = ws_->mat_meta; std::map<const uint8_t*, uint8_t*>& mat_types_ = ws_->mat_types;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
     int nparts_d_ = 1;
