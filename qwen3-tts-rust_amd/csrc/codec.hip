@@ -212,6 +212,116 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
             }
     }
 }
+// Register-blocked form of the split-f16 GEMM for large M: the 4 waves of a workgroup stack along M and each wave owns MR x NT tiles of
+// 32 x 32 (workgroup tile (128 MR) x (32 NT); MR = 2, NT = 3 -> 256 x 96, and every channel count of the decoder is 96 * 2^k, so no column of
+// a tile is padding).  Why: in k_conv_gemm_h<1> a wave reads 4 LDS fragments (a_hi, a_lo, b_hi, b_lo) for 3 matrix instructions -- the LDS
+// pipe (128 B/clk per CU) is busy longer than the matrix pipe, and every 64 x 64 output tile re-streams its 64-column weight panel (for the
+// N = 96 stage at 245 760 rows that is 1.3 GB of L2 -> LDS weight traffic per launch against 94 MB of activations).  Here a k-step of 16 reads
+// 2 MR + 2 NT = 10 fragments for 3 MR NT = 18 matrix instructions, and the weight panel is read once per 256 rows.
+template <int MR, int NT>
+__global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
+    constexpr int BM = 128 * MR, BN = 32 * NT, BK = 32, LD = 40;
+    constexpr int NA = BM * 8 / 256;             // float4 fetches of A per thread per K tile
+    constexpr int NB = (BN * 4 + 255) / 256;     // uint4 fetches of B (hi and lo each) per thread per K tile
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    f32x16 acc[MR][NT];
+#pragma unroll
+    for (int t = 0; t < MR; t++)
+#pragma unroll
+        for (int u = 0; u < NT; u++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+    float4 ra[NA];
+    uint4 rh[NB], rl[NB];
+    int arow[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    auto fetch = [&](int k0) {
+        const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
+            if (e < BN * 4 && n0 + r < g.N) {
+                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
+                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            h4v hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
+            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stash();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
+            h8v bh[NT], bl[NT];
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                bh[u] = *reinterpret_cast<const h8v*>(&Bh[u * 32 + (lane & 31)][ko]);
+                bl[u] = *reinterpret_cast<const h8v*>(&Bl[u * 32 + (lane & 31)][ko]);
+            }
+#pragma unroll
+            for (int t = 0; t < MR; t++) {
+                const int ar = (wave * MR + t) * 32 + (lane & 31);
+                const h8v ah = *reinterpret_cast<const h8v*>(&Ah[ar][ko]);
+                const h8v al = *reinterpret_cast<const h8v*>(&Al[ar][ko]);
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], acc[t][u], 0, 0, 0);
+                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[t][u], 0, 0, 0);
+                }
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+        const int col = n0 + u * 32 + (lane & 31);
+        if (col >= g.N) continue;
+#pragma unroll
+        for (int t = 0; t < MR; t++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) {
+                const int row = m0 + (wave * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                if (row < g.M) {
+                    if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][u][r];
+                    else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[t][u][r], row, col);
+                }
+            }
+    }
+}
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)g.M * g.N) return;
@@ -287,6 +397,19 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     while (tiles * ksplit < 256 && ksplit < 16 && (g.K / (ksplit * 2)) % 16 == 0 && g.K / (ksplit * 2) >= 128 &&
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
+    static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 2048; }(); // 0 = never
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0) { // register-blocked 256 x 96 tiles
+        const int t2 = (g.N / 96) * ((g.M + 255) / 256);
+        static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }();
+        int ks = 1;
+        while (t2 * ks < wg_target && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
+        hipLaunchKernelGGL((k_conv_gemm_h2<2, 3>), dim3(g.N / 96, (g.M + 255) / 256, ks), dim3(256), 0, st, g, wh, wl);
+        if (ks > 1) {
+            const size_t n = (size_t)g.M * g.N;
+            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
+        }
+        return;
+    }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
         static const int big_m = [] { const char* e = std::getenv("Q3_CODEC_BM128"); return e ? atoi(e) : 1024; }(); // rows from which the 128-row tile is used
         // measured inside the 64-stream pipeline: N = 768 (K = 5376) 96 -> 64 us with the tall tile, N <= 384 no gain
