@@ -237,34 +237,34 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
         for (int u = 0; u < NT; u++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
-    float4 ra[NA];
-    uint4 rh[NB], rl[NB];
+    float4 ra[2][NA]; // two K tiles in flight (the second set hides the ~2 us HBM latency of the activations behind two compute steps)
+    uint4 rh[2][NB], rl[2][NB];
     int arow[NA];
 #pragma unroll
     for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
-    auto fetch = [&](int k0) {
+    auto fetch = [&](int k0, float4* ra_, uint4* rh_, uint4* rl_) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+            ra_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < g.M) ra_[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
+            rh_[i] = make_uint4(0, 0, 0, 0); rl_[i] = make_uint4(0, 0, 0, 0);
             if (e < BN * 4 && n0 + r < g.N) {
-                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
-                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
+                rh_[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
+                rl_[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
             }
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](const float4* ra_, const uint4* rh_, const uint4* rl_) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            const float x[4] = {ra_[i].x, ra_[i].y, ra_[i].z, ra_[i].w};
             h4v hi, lo;
 #pragma unroll
             for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
@@ -274,14 +274,10 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
+            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh_[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl_[i]; }
         }
     };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
+    auto compute = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
@@ -304,7 +300,22 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
                 }
             }
         }
+    };
+    fetch(kbeg, ra[0], rh[0], rl[0]);
+    if (kbeg + BK < kend) fetch(kbeg + BK, ra[1], rh[1], rl[1]);
+    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) { // two K tiles per iteration so the register sets alternate at compile time
+        stash(ra[0], rh[0], rl[0]);
         __syncthreads();
+        if (k0 + 2 * BK < kend) fetch(k0 + 2 * BK, ra[0], rh[0], rl[0]);
+        compute();
+        __syncthreads();
+        if (k0 + BK < kend) {
+            stash(ra[1], rh[1], rl[1]);
+            __syncthreads();
+            if (k0 + 3 * BK < kend) fetch(k0 + 3 * BK, ra[1], rh[1], rl[1]);
+            compute();
+            __syncthreads();
+        }
     }
 #pragma unroll
     for (int u = 0; u < NT; u++) {
@@ -398,7 +409,8 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
     static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 2048; }(); // 0 = never
-    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0) { // register-blocked 256 x 96 tiles
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
+        (g.N / 96) * ((g.M + 255) / 256) >= 128) { // register-blocked 256 x 96 tiles, when they still make >= 128 workgroups before split-K
         const int t2 = (g.N / 96) * ((g.M + 255) / 256);
         static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }();
         int ks = 1;
