@@ -408,7 +408,11 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     while (tiles * ksplit < 256 && ksplit < 16 && (g.K / (ksplit * 2)) % 16 == 0 && g.K / (ksplit * 2) >= 128 &&
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
-    static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 2048; }(); // 0 = never
+    // Opt-in (Q3_CODEC_H2_MINM=2048): measured on MI355X the register-blocked form LOSES to the 64 x 64 form -- codec alone at 32 streams
+    // 10.3 vs 6.8 ms per 4-frame pass (995 vs 1505 audio-s/s) with two K tiles in flight, 7.6 ms with one: 248 VGPRs and 56 KB of LDS leave two
+    // workgroups per CU, and a barrier-synchronous main loop with two workgroups cannot hide the ~2 us activation latency that eight
+    // 44-register workgroups of the small-tile form hide by sheer occupancy.  The big tile needs a barrier-free pipelined main loop to pay.
+    static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 0; }(); // 0 = never
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
         (g.N / 96) * ((g.M + 255) / 256) >= 128) { // register-blocked 256 x 96 tiles, when they still make >= 128 workgroups before split-K
         const int t2 = (g.N / 96) * ((g.M + 255) / 256);

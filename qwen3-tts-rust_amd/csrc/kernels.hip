@@ -587,32 +587,37 @@ __global__ void Q3_GEMM2_BUDGET k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, co
     constexpr int MAGIC = 0x3E22F983;
     const float c0 = __int_as_float(MAGIC);
     const f32x2v negc0 = f32x2v{-c0, -c0};
-    i32x4v wv[NM][8];
-    uint4 dwv[NM];
-    if (active) {
-#pragma unroll
-        for (int q = 0; q < NM; q++) {
-            int row = row0 + blockIdx.x * 32 + r + q * ff;
-            if (row > w.Npad - 1) row = w.Npad - 1;
-            const int rg = row >> 5, r32 = row & 31;
-            const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-#pragma unroll
-            for (int i = 0; i < 8; i++) wv[q][i] = (ABL & 4) ? i32x4v{lane, i, q, 1} : *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
-            dwv[q] = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
-        }
-    }
-    // A operand: this lane feeds token (lane & 31), k-half (lane >> 5); dx: that token's 8 block scales
+    // Issue order = arrival order the compute loop wants: the (L2-resident) activations and the scale vectors first, then the weight blocks in
+    // the order the block pairs consume them, gate and up interleaved -- the first matrix instructions start while later weight blocks are
+    // still streaming in (the compiler places counted s_waitcnt vmcnt before each first use), instead of after the last load has landed.
     i32x4v av[8];
     uint4 dxa = make_uint4(0, 0, 0, 0);
     auto load_x = [&](int tt, i32x4v* a, uint4& dx) {
         int atok = tt * 32 + r;
         if (atok > ntok - 1) atok = ntok - 1;
         const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+        dx = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8);
 #pragma unroll
         for (int i = 0; i < 8; i++) a[i] = (ABL & 2) ? i32x4v{lane, i, tt, 2} : *reinterpret_cast<const i32x4v*>(xp + i * 32);
-        dx = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8);
     };
-    if (active) load_x(blockIdx.z, av, dxa);
+    i32x4v wv[NM][8];
+    uint4 dwv[NM];
+    if (active) {
+        const uint8_t* base[NM];
+#pragma unroll
+        for (int q = 0; q < NM; q++) {
+            int row = row0 + blockIdx.x * 32 + r + q * ff;
+            if (row > w.Npad - 1) row = w.Npad - 1;
+            const int rg = row >> 5, r32 = row & 31;
+            base[q] = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+            dwv[q] = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+        }
+        load_x(blockIdx.z, av, dxa);
+#pragma unroll
+        for (int i = 0; i < 8; i++)
+#pragma unroll
+            for (int q = 0; q < NM; q++) wv[q][i] = (ABL & 4) ? i32x4v{lane, i, q, 1} : *reinterpret_cast<const i32x4v*>(base[q] + (size_t)i * 1024);
+    }
     // B operand of the scale outer product: lanes 0..31 feed block 2p, lanes 32..63 block 2p + 1, with the 2^26 of the magic offset folded in
     float ew[NM][4];
 #pragma unroll

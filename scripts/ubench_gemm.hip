@@ -38,12 +38,14 @@ static void run_wave(const Q8Mat& m, int nrows, int ff, const int8_t* xq, const 
     printf("    %-34s %7.2f us  (%d waves)\n", "wave-per-tile form", us, rgs * (GU ? 1 : nsseg) * ((ntok + 31) / 32));
 }
 
-int main() {
+int main(int argc, char** argv) {
+    const bool quick = argc > 1 && !strcmp(argv[1], "quick"); // production launcher only, talker shapes at 64 / 256 tokens (for PMC passes)
     struct Shape { const char* name; int n, k, gu; } shapes[] = {
         {"talker gate/up 12288x2048", 12288, 2048, 1}, {"talker down 2048x6144", 2048, 6144, 0}, {"talker qkv 4096x2048", 4096, 2048, 0},
         {"talker o 2048x2048", 2048, 2048, 0}, {"pred gate/up 6144x1024", 6144, 1024, 1}, {"pred qkv 4096x1024", 4096, 1024, 0},
         {"pred o 1024x2048", 1024, 2048, 0}, {"pred down 1024x3072", 1024, 3072, 0}};
     for (auto& sh : shapes) {
+        if (quick && &sh - shapes > 1) break;
         const int n = sh.n, k = sh.k;
         std::vector<uint8_t> raw((size_t)n * (k / 32) * 34);
         for (size_t i = 0; i < raw.size(); i++) raw[i] = (uint8_t)(i * 2654435761u >> 13);
@@ -51,6 +53,7 @@ int main() {
         DevBuf<uint8_t> storage;
         Q8Mat m = q8mat_from_host(raw.data(), n, k, storage);
         for (int ntok : {64, 128, 256, 512}) {
+            if (quick && ntok != 64 && ntok != 256) continue;
             DevBuf<int8_t> xq((size_t)ntok * k); DevBuf<uint16_t> xd((size_t)ntok * k / 32);
             std::vector<int8_t> hx(xq.n); for (size_t i = 0; i < hx.size(); i++) hx[i] = (int8_t)((i * 40503u >> 7) & 0xFF);
             std::vector<uint16_t> hd(xd.n, 0x2000);
@@ -64,6 +67,7 @@ int main() {
                 else launch_gemv_q8(0, m, 0, n, xq.p, xd.p, out.p, n, ntok);
             });
             printf("    %-34s %7.2f us  (%.2f TB/s)\n", "production launcher", us, mb / us);
+            if (quick) continue;
             if (sh.gu) run_wave<true>(m, n, ff, xq.p, xd.p, out.p, aq.p, ad.p, ntok); else run_wave<false>(m, n, ff, xq.p, xd.p, out.p, aq.p, ad.p, ntok);
             if (ntok != 64 && ntok != 256) continue;
             const int ntiles = (ntok + 31) / 32;
