@@ -205,6 +205,14 @@ int q3tts_decoder_reset(q3tts_decoder* d, int32_t stream);
 int q3tts_decoder_decode(q3tts_decoder* d, int32_t stream, const int64_t* codes, int32_t n_frames, int32_t is_last,
                          float* final_wav, int64_t* valid_samples);
 
+/* DecoderState (onnx.rs:461-496) export / import: one stream's streaming state as a flat f32 blob whose layout is a list of named tensors
+ * (pre_conv_history, past_key_i / past_value_i, the conv_history pieces, counters) -- to checkpoint a stream, move it to another decoder
+ * or device, or inspect it.  q3tts_decoder_state_entry(i) describes entry i and returns the entry count. */
+int64_t q3tts_decoder_state_floats(q3tts_decoder* d);
+int q3tts_decoder_state_export(q3tts_decoder* d, int32_t stream, float* out);
+int q3tts_decoder_state_import(q3tts_decoder* d, int32_t stream, const float* in);
+int32_t q3tts_decoder_state_entry(q3tts_decoder* d, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols);
+
 /* ---- mel front end (device) ---- */
 int q3tts_mel_frames(int32_t n_samples);
 int q3tts_mel(const float* audio, int32_t n_samples, float* mel_out /* [frames][128] */);

@@ -912,6 +912,59 @@ void CodecDecoder::reset(int s) {
     m.kv_len[s] = 0; m.n_seen[s] = 0;
 }
 
+// ---- DecoderState export / import (onnx.rs:461-496: the reference carries the streaming state as named tensors between decode calls;
+// here it lives on the device, and these calls move one stream's state out / in as a flat f32 blob with a published layout) ----
+std::vector<CodecStateEntry> CodecDecoder::state_layout() const {
+    const Impl& m = *impl_;
+    std::vector<CodecStateEntry> out;
+    size_t off = 0;
+    auto add = [&](const std::string& name, const Ext& e) {
+        if (!e.H) return;
+        out.push_back(CodecStateEntry{name, (int64_t)off, e.H, e.C});
+        off += (size_t)e.H * e.C;
+    };
+    add("pre_conv_history", m.z_ext);                                   // onnx.rs:476 (rows = time, columns = channels)
+    for (size_t l = 0; l < m.k_ext.size(); l++) { add("past_key_" + std::to_string(l), m.k_ext[l]); add("past_value_" + std::to_string(l), m.v_ext[l]); } // :484-492
+    for (size_t i = 0; i < m.dw_ext.size(); i++) add("conv_history.upsample." + std::to_string(i), m.dw_ext[i]);            // :480 conv_history, split
+    add("conv_history.conv_in", m.convin_ext);
+    for (size_t b = 0; b < m.ct_ext.size(); b++) {
+        add("conv_history.block." + std::to_string(b) + ".transposed", m.ct_ext[b]);
+        for (size_t u = 0; u < m.ru_ext[b].size(); u++) add("conv_history.block." + std::to_string(b) + ".unit." + std::to_string(u), m.ru_ext[b][u]);
+    }
+    add("conv_history.conv_out", m.out_ext);
+    out.push_back(CodecStateEntry{"counters(kv_len,frames_seen)", (int64_t)off, 1, 2});
+    return out;
+}
+size_t CodecDecoder::state_floats() const { const auto l = state_layout(); return (size_t)l.back().offset + 2; }
+void CodecDecoder::state_export(int s, float* out) const {
+    const Impl& m = *impl_;
+    Q3_CHECK(s >= 0 && s < m.n_streams && out, "stream out of range");
+    Q3_HIP(hipDeviceSynchronize()); // the stream's pending decodes must have landed
+    size_t off = 0;
+    auto one = [&](const Ext& e) { if (!e.H) return; const size_t n = (size_t)e.H * e.C; Q3_HIP(hipMemcpy(out + off, e.hist.p + (size_t)s * n, n * 4, hipMemcpyDeviceToHost)); off += n; };
+    one(m.z_ext);
+    for (size_t l = 0; l < m.k_ext.size(); l++) { one(m.k_ext[l]); one(m.v_ext[l]); }
+    for (auto& e : m.dw_ext) one(e);
+    one(m.convin_ext);
+    for (size_t b = 0; b < m.ct_ext.size(); b++) { one(m.ct_ext[b]); for (auto& e : m.ru_ext[b]) one(e); }
+    one(m.out_ext);
+    out[off] = (float)m.kv_len[s]; out[off + 1] = (float)m.n_seen[s];
+}
+void CodecDecoder::state_import(int s, const float* in) {
+    Impl& m = *impl_;
+    Q3_CHECK(s >= 0 && s < m.n_streams && in, "stream out of range");
+    Q3_HIP(hipDeviceSynchronize());
+    size_t off = 0;
+    auto one = [&](Ext& e) { if (!e.H) return; const size_t n = (size_t)e.H * e.C; Q3_HIP(hipMemcpy(e.hist.p + (size_t)s * n, in + off, n * 4, hipMemcpyHostToDevice)); off += n; };
+    one(m.z_ext);
+    for (size_t l = 0; l < m.k_ext.size(); l++) { one(m.k_ext[l]); one(m.v_ext[l]); }
+    for (auto& e : m.dw_ext) one(e);
+    one(m.convin_ext);
+    for (size_t b = 0; b < m.ct_ext.size(); b++) { one(m.ct_ext[b]); for (auto& e : m.ru_ext[b]) one(e); }
+    one(m.out_ext);
+    m.kv_len[s] = (int)in[off]; m.n_seen[s] = (long long)in[off + 1];
+}
+
 void CodecDecoder::reset_async(hipStream_t st, int s) {
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");

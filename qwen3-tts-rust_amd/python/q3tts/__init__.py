@@ -70,6 +70,7 @@ SYMBOLS = [
     "q3tts_comm_destroy", "q3tts_comm_voice_register", "q3tts_engine_device",
     "q3tts_onnx_open", "q3tts_onnx_close", "q3tts_onnx_counts", "q3tts_onnx_summary", "q3tts_onnx_node", "q3tts_onnx_node_input", "q3tts_onnx_node_output",
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
+    "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
 
@@ -451,6 +452,31 @@ class Decoder:  # AudioDecoder (onnx.rs:324-496)
         _chk(lib().q3tts_decoder_decode(self.h, stream, _p(codes), codes.shape[0], 1 if is_last else 0, _p(wav), C.byref(valid)))
         return wav[: valid.value]
 
+
+    def state_export(self, stream=0):
+        L = lib()
+        L.q3tts_decoder_state_floats.restype = C.c_int64
+        L.q3tts_decoder_state_floats.argtypes = [C.c_void_p]
+        L.q3tts_decoder_state_export.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        buf = np.zeros(L.q3tts_decoder_state_floats(self.h), np.float32)
+        _chk(L.q3tts_decoder_state_export(self.h, stream, _p(buf)))
+        return buf
+
+    def state_import(self, blob, stream=0):
+        lib().q3tts_decoder_state_import.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        blob = np.ascontiguousarray(blob, np.float32)
+        _chk(lib().q3tts_decoder_state_import(self.h, stream, _p(blob)))
+
+    def state_layout(self):
+        L = lib()
+        L.q3tts_decoder_state_entry.argtypes = [C.c_void_p, C.c_int32, C.POINTER(C.c_char_p), C.POINTER(C.c_int64), C.POINTER(C.c_int32), C.POINTER(C.c_int32)]
+        n = L.q3tts_decoder_state_entry(self.h, -1, None, None, None, None)
+        out = []
+        for i in range(n):
+            nm, off, r, c = C.c_char_p(), C.c_int64(), C.c_int32(), C.c_int32()
+            L.q3tts_decoder_state_entry(self.h, i, C.byref(nm), C.byref(off), C.byref(r), C.byref(c))
+            out.append((nm.value.decode(), off.value, r.value, c.value))
+        return out
 
     def decode_group(self, streams, codes):
         """codes [G][n_frames][16] for G distinct streams -> wav [G][n_frames*spf] (one decode pass for the whole group)"""

@@ -692,3 +692,25 @@ def test_group_api_voice_broadcast_and_round_robin(gpu, tiny_model, tmp_path, n_
     ge.close()
     assert np.array_equal(np.array(lines["CLONE"], np.int32).reshape(-1, 16), ref["codes"])
     assert int(lines["PCM"][0]) == 6 * 1920 or int(lines["PCM"][0]) > 0
+
+
+def test_decoder_state_export_import(gpu, tiny_model):
+    """DecoderState (onnx.rs:461-496) as named tensors out of / into the device: a stream checkpointed after one chunk and restored into a
+    DIFFERENT stream slot of another decoder continues bit-identically; the layout names the reference's state tensors."""
+    path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
+    rng = np.random.default_rng(31)
+    codes = rng.integers(0, 2048, (12, 16))
+    a = gpu.Decoder(path, n_streams=2)
+    a.reset(0)
+    head = a.decode(codes[:4], stream=0).copy()
+    blob = a.state_export(0)
+    tail_ref = a.decode(codes[4:], stream=0).copy()
+    names = [e[0] for e in a.state_layout()]
+    assert names[0] == "pre_conv_history" and "past_key_0" in names and "past_value_0" in names and any(n.startswith("conv_history.") for n in names)
+    assert names[-1].startswith("counters") and blob.size == a.state_layout()[-1][1] + 2 and blob[-1] == 4.0
+    b = gpu.Decoder(path, n_streams=3)
+    b.reset(2)
+    b.state_import(blob, stream=2)
+    tail = b.decode(codes[4:], stream=2).copy()
+    assert np.array_equal(tail, tail_ref) and head.size == 4 * a.spf
+    a.close(); b.close()
