@@ -333,6 +333,108 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
             }
     }
 }
+// LDS-window form of the 7-tap dilated convolutions of the narrow decoder stages (cin = cout = C in {96, 192}; K = 7 C).
+// Why (profiles/r02_hbm_traffic_pmc.md, gpurun codec traces): the implicit-GEMM forms above walk K tap-major, so a workgroup sweeps its A rows
+// once per tap in 128-byte column strips and relies on L2 to keep them; at 245 760 rows the N = 96 stage fetches 395 MB from HBM per launch for
+// 94 MB of activations (and the 256 x 96 register-blocked tile, whose window no longer fits the L2 next to its neighbours', is bound by exactly
+// that: 2.4 TB/s of misses, 397 us).  Here a workgroup copies its BM + 6 dil input rows ONCE into LDS (as the hi / lo f16 planes the split-f16
+// MFMA needs), forms the 7 taps from that window, and streams only the (L2-resident, 258 KB / 1 MB) weights through a small LDS tile:
+// every input row is read once from HBM (plus the 6 dil halo rows per tile).  4 waves; C = 96: BM = 128, a wave owns 32 rows x all 96 columns;
+// C = 192: BM = 64, a wave owns 32 rows x 96 columns.  Same products, same accumulation structure per output as k_conv_gemm_h (f32 accumulate of
+// a_lo b_hi + a_hi b_lo + a_hi b_hi over K in the same K order), same epilogues.
+template <int C, int BM>
+__global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
+    constexpr int NCG = C / 96, NRT = BM / 32, NT = 3, BK = 32, LDB = 40;
+    static_assert(NCG * NRT == 4, "4 waves = row tiles x column groups");
+    constexpr int LDW = C + 8;                     // halfs per window row: 16-byte pad keeps the 8-lane groups of a b128 read on distinct banks
+    constexpr int WMAX = BM + 54;                  // dil <= 9
+    constexpr int NB = (C * 4 + 255) / 256;        // uint4 fetches of B (hi and lo each) per thread per K tile
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
+    _Float16* Ah = reinterpret_cast<_Float16*>(smem_w);                   // [WMAX][LDW]
+    _Float16* Al = Ah + (size_t)WMAX * LDW;                               // [WMAX][LDW]
+    _Float16* Bh = Al + (size_t)WMAX * LDW;                               // [C][LDB]
+    _Float16* Bl = Bh + (size_t)C * LDB;                                  // [C][LDB]
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int rt = wave % NRT, cg = wave / NRT;
+    const int m0 = blockIdx.x * BM;
+    const int wrows = BM + 6 * g.dil;
+    const size_t base_row = (size_t)m0 + (size_t)(m0 / g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
+    uint4 rh[NB], rl[NB];
+    auto fetch_b = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
+            if (e < C * 4) {
+                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)r * g.K + k0 + wk);
+                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)r * g.K + k0 + wk);
+            }
+        }
+    };
+    fetch_b(0);
+    // the window: (BM + 6 dil) rows x C channels, f32 -> hi / lo f16, one pass over HBM
+    for (int e = tid; e < wrows * (C / 4); e += 256) {
+        const int r = e / (C / 4), c4 = e % (C / 4);
+        const float4 v = *reinterpret_cast<const float4*>(g.A + (base_row + r) * g.lda + 4 * c4);
+        const float x[4] = {v.x, v.y, v.z, v.w};
+        h4v hi, lo;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+        *reinterpret_cast<h4v*>(Ah + (size_t)r * LDW + 4 * c4) = hi;
+        *reinterpret_cast<h4v*>(Al + (size_t)r * LDW + 4 * c4) = lo;
+    }
+    f32x16 acc[NT];
+#pragma unroll
+    for (int u = 0; u < NT; u++)
+#pragma unroll
+        for (int i = 0; i < 16; i++) acc[u][i] = 0.0f;
+    for (int k0 = 0; k0 < g.K; k0 += BK) {
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            if (e < C * 4) { *reinterpret_cast<uint4*>(Bh + (size_t)r * LDB + wk) = rh[i]; *reinterpret_cast<uint4*>(Bl + (size_t)r * LDB + wk) = rl[i]; }
+        }
+        __syncthreads(); // (first iteration: also publishes the window)
+        if (k0 + BK < g.K) fetch_b(k0 + BK);
+        const int j = k0 / C, ci0 = k0 % C;      // tap, first channel of this K tile (BK divides C)
+        const int arow = rt * 32 + (lane & 31) + j * g.dil;
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const int ko = kk + 8 * (lane >> 5);
+            const h8v ah = *reinterpret_cast<const h8v*>(Ah + (size_t)arow * LDW + ci0 + ko);
+            const h8v al = *reinterpret_cast<const h8v*>(Al + (size_t)arow * LDW + ci0 + ko);
+#pragma unroll
+            for (int u = 0; u < NT; u++) {
+                const int brow = (cg * NT + u) * 32 + (lane & 31);
+                const h8v bh = *reinterpret_cast<const h8v*>(Bh + (size_t)brow * LDB + ko);
+                const h8v bl = *reinterpret_cast<const h8v*>(Bl + (size_t)brow * LDB + ko);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u], 0, 0, 0);
+                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
+            }
+        }
+        __syncthreads();
+    }
+#pragma unroll
+    for (int u = 0; u < NT; u++) {
+        const int col = (cg * NT + u) * 32 + (lane & 31);
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[u][r], row, col);
+        }
+    }
+}
+template <int C, int BM> static size_t conv7_win_lds() { return ((size_t)(BM + 54) * (C + 8) * 2 + (size_t)C * 40 * 2) * sizeof(_Float16); }
+static void init_codec_kernel_attributes() { // dynamic LDS above 64 KiB needs a per-device opt-in (done at decoder construction)
+    static bool done[64] = {};
+    int dev = 0;
+    Q3_HIP(hipGetDevice(&dev));
+    if (dev < 0 || dev > 63 || done[dev]) return;
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7_win_h<96, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv7_win_lds<96, 128>()));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7_win_h<192, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv7_win_lds<192, 64>()));
+    done[dev] = true;
+}
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)g.M * g.N) return;
@@ -412,6 +514,17 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     // 10.3 vs 6.8 ms per 4-frame pass (995 vs 1505 audio-s/s) with two K tiles in flight, 7.6 ms with one: 248 VGPRs and 56 KB of LDS leave two
     // workgroups per CU, and a barrier-synchronous main loop with two workgroups cannot hide the ~2 us activation latency that eight
     // 44-register workgroups of the small-tile form hide by sheer occupancy.  The big tile needs a barrier-free pipelined main loop to pay.
+    // 7-tap convolutions of the narrow stages: LDS-window form (every input row read once)
+    static const int win_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_WIN_MIN_WGS"); return e ? atoi(e) : 256; }(); // 0 = never
+    if (wh && !g_codec_f32 && win_min_wgs > 0 && g.cin == g.N && g.K == 7 * g.cin && g.dil <= 9 && (g.N == 96 || g.N == 192)) {
+        const int bm = g.N == 96 ? 128 : 64;
+        if (g.M % bm == 0 && (g.a_segT == SEG_NONE || g.a_segT % bm == 0) && g.M / bm >= win_min_wgs) {
+            const size_t lds96 = conv7_win_lds<96, 128>(), lds192 = conv7_win_lds<192, 64>();
+            if (g.N == 96) hipLaunchKernelGGL((k_conv7_win_h<96, 128>), dim3(g.M / bm), dim3(256), lds96, st, g, wh, wl);
+            else hipLaunchKernelGGL((k_conv7_win_h<192, 64>), dim3(g.M / bm), dim3(256), lds192, st, g, wh, wl);
+            return;
+        }
+    }
     static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 0; }(); // 0 = never
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
         (g.N / 96) * ((g.M + 255) / 256) >= 128) { // register-blocked 256 x 96 tiles, when they still make >= 128 workgroups before split-K
@@ -756,6 +869,7 @@ struct CodecDecoder::Impl {
 };
 
 CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes, int max_group) : impl_(new Impl()) {
+    init_codec_kernel_attributes();
     Impl& m = *impl_;
     Gguf g(path);
     m.n_streams = n_streams; m.max_frames = max_frames; m.gmax = max_group > 0 ? max_group : 1;
