@@ -359,19 +359,24 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
     const int m0 = blockIdx.x * BM;
     const int wrows = BM + 6 * g.dil;
     const size_t base_row = (size_t)m0 + (size_t)(m0 / g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
-    uint4 rh[NB], rl[NB];
-    auto fetch_b = [&](int k0) {
+    // The weight tiles come from L2 / the memory-side cache at ~2 us per round trip, and with the window in LDS only ONE workgroup (one wave
+    // per SIMD) fits a CU -- nothing else hides that latency.  So the weights run DEPTH K tiles ahead in registers (a wave alone on its SIMD has
+    // 512 of them): measured with one tile ahead, a K step took 5.6k cycles for 576 cycles of matrix work.  K / 32 is a multiple of 7 (K = 7 C).
+    constexpr int DEPTH = 7;
+    uint4 rh[DEPTH][NB], rl[DEPTH][NB];
+    auto fetch_b = [&](int k0, uint4* rh_, uint4* rl_) {
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
-            if (e < C * 4) {
-                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)r * g.K + k0 + wk);
-                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)r * g.K + k0 + wk);
+            rh_[i] = make_uint4(0, 0, 0, 0); rl_[i] = make_uint4(0, 0, 0, 0);
+            if (e < C * 4 && k0 < g.K) {
+                rh_[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)r * g.K + k0 + wk);
+                rl_[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)r * g.K + k0 + wk);
             }
         }
     };
-    fetch_b(0);
+#pragma unroll
+    for (int d = 0; d < DEPTH; d++) fetch_b(d * BK, rh[d], rl[d]);
     // the window: (BM + 6 dil) rows x C channels, f32 -> hi / lo f16, one pass over HBM
     for (int e = tid; e < wrows * (C / 4); e += 256) {
         const int r = e / (C / 4), c4 = e % (C / 4);
@@ -388,32 +393,36 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
     for (int u = 0; u < NT; u++)
 #pragma unroll
         for (int i = 0; i < 16; i++) acc[u][i] = 0.0f;
-    for (int k0 = 0; k0 < g.K; k0 += BK) {
+    for (int kb = 0; kb < g.K; kb += DEPTH * BK) {
 #pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            if (e < C * 4) { *reinterpret_cast<uint4*>(Bh + (size_t)r * LDB + wk) = rh[i]; *reinterpret_cast<uint4*>(Bl + (size_t)r * LDB + wk) = rl[i]; }
-        }
-        __syncthreads(); // (first iteration: also publishes the window)
-        if (k0 + BK < g.K) fetch_b(k0 + BK);
-        const int j = k0 / C, ci0 = k0 % C;      // tap, first channel of this K tile (BK divides C)
-        const int arow = rt * 32 + (lane & 31) + j * g.dil;
+        for (int d = 0; d < DEPTH; d++) {
+            const int k0 = kb + d * BK;
 #pragma unroll
-        for (int kk = 0; kk < BK; kk += 16) {
-            const int ko = kk + 8 * (lane >> 5);
-            const h8v ah = *reinterpret_cast<const h8v*>(Ah + (size_t)arow * LDW + ci0 + ko);
-            const h8v al = *reinterpret_cast<const h8v*>(Al + (size_t)arow * LDW + ci0 + ko);
-#pragma unroll
-            for (int u = 0; u < NT; u++) {
-                const int brow = (cg * NT + u) * 32 + (lane & 31);
-                const h8v bh = *reinterpret_cast<const h8v*>(Bh + (size_t)brow * LDB + ko);
-                const h8v bl = *reinterpret_cast<const h8v*>(Bl + (size_t)brow * LDB + ko);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u], 0, 0, 0);
-                acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
+            for (int i = 0; i < NB; i++) {
+                const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+                if (e < C * 4) { *reinterpret_cast<uint4*>(Bh + (size_t)r * LDB + wk) = rh[d][i]; *reinterpret_cast<uint4*>(Bl + (size_t)r * LDB + wk) = rl[d][i]; }
             }
+            __syncthreads(); // (first iteration: also publishes the window)
+            fetch_b(k0 + DEPTH * BK, rh[d], rl[d]);
+            const int j = k0 / C, ci0 = k0 % C;      // tap, first channel of this K tile (BK divides C)
+            const int arow = rt * 32 + (lane & 31) + j * g.dil;
+#pragma unroll
+            for (int kk = 0; kk < BK; kk += 16) {
+                const int ko = kk + 8 * (lane >> 5);
+                const h8v ah = *reinterpret_cast<const h8v*>(Ah + (size_t)arow * LDW + ci0 + ko);
+                const h8v al = *reinterpret_cast<const h8v*>(Al + (size_t)arow * LDW + ci0 + ko);
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const int brow = (cg * NT + u) * 32 + (lane & 31);
+                    const h8v bh = *reinterpret_cast<const h8v*>(Bh + (size_t)brow * LDB + ko);
+                    const h8v bl = *reinterpret_cast<const h8v*>(Bl + (size_t)brow * LDB + ko);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u], 0, 0, 0);
+                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
+                }
+            }
+            __syncthreads();
         }
-        __syncthreads();
     }
 #pragma unroll
     for (int u = 0; u < NT; u++) {
