@@ -359,10 +359,10 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
     const int m0 = blockIdx.x * BM;
     const int wrows = BM + 6 * g.dil;
     const size_t base_row = (size_t)m0 + (size_t)(m0 / g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
-    // The weight tiles come from L2 / the memory-side cache at ~2 us per round trip, and with the window in LDS only ONE workgroup (one wave
-    // per SIMD) fits a CU -- nothing else hides that latency.  So the weights run DEPTH K tiles ahead in registers (a wave alone on its SIMD has
-    // 512 of them): measured with one tile ahead, a K step took 5.6k cycles for 576 cycles of matrix work.  K / 32 is a multiple of 7 (K = 7 C).
-    constexpr int DEPTH = 7;
+    // With the window in LDS only ONE workgroup (one wave per SIMD) fits a CU, so nothing but the wave's own loads in flight hides latency:
+    // the weight tiles run DEPTH K tiles ahead in registers (K / 32 is a multiple of 3: K = 7 C, C = 96 or 192), and the window is fetched
+    // with ALL its loads issued before the first conversion (a rolled loop paid one ~2 us HBM round trip per iteration: 34 us per workgroup).
+    constexpr int DEPTH = 3;
     uint4 rh[DEPTH][NB], rl[DEPTH][NB];
     auto fetch_b = [&](int k0, uint4* rh_, uint4* rl_) {
 #pragma unroll
@@ -378,15 +378,28 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
 #pragma unroll
     for (int d = 0; d < DEPTH; d++) fetch_b(d * BK, rh[d], rl[d]);
     // the window: (BM + 6 dil) rows x C channels, f32 -> hi / lo f16, one pass over HBM
-    for (int e = tid; e < wrows * (C / 4); e += 256) {
-        const int r = e / (C / 4), c4 = e % (C / 4);
-        const float4 v = *reinterpret_cast<const float4*>(g.A + (base_row + r) * g.lda + 4 * c4);
-        const float x[4] = {v.x, v.y, v.z, v.w};
-        h4v hi, lo;
+    {
+        constexpr int NW = (WMAX * (C / 4) + 255) / 256;
+        float4 wv[NW];
+        const int nel = wrows * (C / 4);
 #pragma unroll
-        for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
-        *reinterpret_cast<h4v*>(Ah + (size_t)r * LDW + 4 * c4) = hi;
-        *reinterpret_cast<h4v*>(Al + (size_t)r * LDW + 4 * c4) = lo;
+        for (int i = 0; i < NW; i++) {
+            const int e = tid + i * 256, r = e / (C / 4), c4 = e % (C / 4);
+            wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (e < nel) wv[i] = *reinterpret_cast<const float4*>(g.A + (base_row + r) * g.lda + 4 * c4);
+        }
+#pragma unroll
+        for (int i = 0; i < NW; i++) {
+            const int e = tid + i * 256, r = e / (C / 4), c4 = e % (C / 4);
+            const float x[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
+            h4v hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+            if (e < nel) {
+                *reinterpret_cast<h4v*>(Ah + (size_t)r * LDW + 4 * c4) = hi;
+                *reinterpret_cast<h4v*>(Al + (size_t)r * LDW + 4 * c4) = lo;
+            }
+        }
     }
     f32x16 acc[NT];
 #pragma unroll
