@@ -552,8 +552,12 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     // 10.3 vs 6.8 ms per 4-frame pass (995 vs 1505 audio-s/s) with two K tiles in flight, 7.6 ms with one: 248 VGPRs and 56 KB of LDS leave two
     // workgroups per CU, and a barrier-synchronous main loop with two workgroups cannot hide the ~2 us activation latency that eight
     // 44-register workgroups of the small-tile form hide by sheer occupancy.  The big tile needs a barrier-free pipelined main loop to pay.
-    // 7-tap convolutions of the narrow stages: LDS-window form (every input row read once)
-    static const int win_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_WIN_MIN_WGS"); return e ? atoi(e) : 256; }(); // 0 = never
+    // 7-tap convolutions of the narrow stages: LDS-window form (every input row read once).  Opt-in (Q3_CODEC_WIN_MIN_WGS=256): parity-green and
+    // it does cut the HBM reads, but measured SLOWER than the small-tile form -- N = 96 at 245 760 rows 348 vs 268 us, N = 192 365 vs 238 us,
+    // codec alone at 32 streams 7.06 vs 6.64 ms per pass -- with the weight tiles 1, 3 or 7 K steps ahead, with the window loads rolled or all
+    // in flight, with libm or the short sine in the epilogue: a 91 / 125 KB window leaves ONE workgroup (one wave per SIMD) per CU, and one wave
+    // per SIMD cannot overlap its own LDS reads, matrix instructions, barriers and epilogue the way eight small workgroups overlap each other's.
+    static const int win_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_WIN_MIN_WGS"); return e ? atoi(e) : 0; }(); // 0 = never
     if (wh && !g_codec_f32 && win_min_wgs > 0 && g.cin == g.N && g.K == 7 * g.cin && g.dil <= 9 && (g.N == 96 || g.N == 192)) {
         const int bm = g.N == 96 ? 128 : 64;
         if (g.M % bm == 0 && (g.a_segT == SEG_NONE || g.a_segT % bm == 0) && g.M / bm >= win_min_wgs) {
