@@ -30,10 +30,40 @@ struct GemmArgs {
     // Batched decoding of G streams: row m belongs to segment m / segT.  A rows live in a batched extended buffer whose
     // segments carry a_skip extra (history) rows each; out / res rows get o_skip / r_skip extra FLOATS per segment.
     int a_segT, a_skip; int o_segT; long long o_skip; int r_segT; long long r_skip;
+    // Pre-split operands: a row of C values stored as [C x f16 hi][C x f16 lo] (the same 4 C bytes as C floats; hi = f16(x), lo = f16(x - hi)).
+    // The SnakeBeta producers (k_snake, the EPI_SNAKE epilogue) write this form once, so the split-f16 GEMMs copy it into LDS instead of
+    // redoing two conversions + a subtraction per element for every tap and every column tile (SQ counters: the VALU was 57 % busy in the
+    // N = 96 stage, the matrix pipe 20 %; profiles/r02_codec_sq_counters.md).  Kernels without an f16 path read hi + lo back as f32.
+    int a_split, o_split;
 };
 #define SEG_NONE 0x3fffffff
 
-__device__ __forceinline__ size_t out_off(const GemmArgs& g, int row, int col) { return (size_t)row * g.ldo + (size_t)(row / g.o_segT) * g.o_skip + col; }
+// segment of a row; the unsegmented case (SEG_NONE, a wave-uniform test) skips the ~35-instruction integer division: it sat in the epilogue
+// of every output element and cost more VALU time than the SnakeBeta sine
+__device__ __forceinline__ int seg_of(int row, int segT) { return segT == SEG_NONE ? 0 : row / segT; }
+__device__ __forceinline__ size_t out_off(const GemmArgs& g, int row, int col) { return (size_t)row * g.ldo + (size_t)seg_of(row, g.o_segT) * g.o_skip + col; }
+typedef _Float16 h4v_ __attribute__((ext_vector_type(4)));
+// 4 consecutive channels ci..ci+3 of A row `row` as f32 (split rows: hi + lo)
+__device__ __forceinline__ float4 load_a4(const GemmArgs& g, size_t row, int ci) {
+    if (!g.a_split) return *reinterpret_cast<const float4*>(g.A + row * g.lda + ci);
+    const _Float16* base = reinterpret_cast<const _Float16*>(g.A + row * g.lda);
+    const h4v_ hi = *reinterpret_cast<const h4v_*>(base + ci), lo = *reinterpret_cast<const h4v_*>(base + g.cin + ci);
+    return make_float4((float)hi[0] + (float)lo[0], (float)hi[1] + (float)lo[1], (float)hi[2] + (float)lo[2], (float)hi[3] + (float)lo[3]);
+}
+// the same 4 channels as raw hi / lo halfs packed into a float4's bits (x,y = hi; z,w = lo): the f16 GEMMs stage these without arithmetic
+__device__ __forceinline__ float4 load_a4_split_raw(const GemmArgs& g, size_t row, int ci) {
+    const _Float16* base = reinterpret_cast<const _Float16*>(g.A + row * g.lda);
+    const float2 hi = *reinterpret_cast<const float2*>(base + ci), lo = *reinterpret_cast<const float2*>(base + g.cin + ci);
+    return make_float4(hi.x, hi.y, lo.x, lo.y);
+}
+// result element -> memory: plain f32, or the hi / lo half planes of a split row (row width = g.N values)
+__device__ __forceinline__ void gemm_store(const GemmArgs& g, int row, int col, float v) {
+    const size_t o = out_off(g, row, 0);
+    if (!g.o_split) { g.out[o + col] = v; return; }
+    _Float16* base = reinterpret_cast<_Float16*>(g.out + o);
+    const _Float16 hi = (_Float16)v;
+    base[col] = hi; base[g.N + col] = (_Float16)(v - (float)hi);
+}
 
 // sin(x) for the SnakeBeta activation.  libm's sinf compiles to ~200 VALU instructions with a Payne-Hanek branch -- in a GEMM epilogue that is
 // more work per output than the whole K loop of the narrow stages (16-48 outputs per lane).  This form: two-term Cody-Waite reduction by
@@ -55,8 +85,8 @@ __device__ __forceinline__ float snake_sin(float x) {
 __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int row, int col) {
     if (g.bias) v += g.bias[col];
     if (g.epi == EPI_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752f));
-    else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + (size_t)(row / g.r_segT) * g.r_skip + col] + g.scale[col] * v;
-    else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + (size_t)(row / g.r_segT) * g.r_skip + col] + v;
+    else if (g.epi == EPI_RES_SCALE) v = g.res[(size_t)row * g.ldr + (size_t)seg_of(row, g.r_segT) * g.r_skip + col] + g.scale[col] * v;
+    else if (g.epi == EPI_RES) v = g.res[(size_t)row * g.ldr + (size_t)seg_of(row, g.r_segT) * g.r_skip + col] + v;
     else if (g.epi == EPI_SNAKE) { const float sn = snake_sin(v * g.snake_ea[col]); v = v + g.snake_ib[col] * (sn * sn); }
     return v;
 }
@@ -81,14 +111,14 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
     float4 ra[NA], rb[NB];
     int arow[NA]; // A row of this thread's i-th fetch (tap 0), including the history rows of the segments before it
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) % BM; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) % BM; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e % BM, qd = e / BM;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < BM * 4 && m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * qd);
+            if (e < BM * 4 && m0 + r < g.M) ra[i] = load_a4(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * qd);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
@@ -129,7 +159,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
             const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
             if (row < g.M) {
                 if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[r];
-                else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[r], row, col);
+                else gemm_store(g, row, col, gemm_epilogue(g, acc[r], row, col));
             }
         }
     }
@@ -162,7 +192,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
     uint4 rh, rl;
     int arow[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
     const int wrow = n0 + tid / 4, wk = 8 * (tid & 3);
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
@@ -170,7 +200,8 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) ra[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+            if (m0 + r < g.M) ra[i] = g.a_split ? load_a4_split_raw(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * kq)
+                                                : *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
         }
         rh = make_uint4(0, 0, 0, 0); rl = make_uint4(0, 0, 0, 0);
         if (wrow < g.N) {
@@ -182,6 +213,11 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            if (g.a_split) { // operands arrive as hi / lo halfs: a copy
+                *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(ra[i].z, ra[i].w);
+                continue;
+            }
             const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
             h4v hi, lo;
 #pragma unroll
@@ -223,10 +259,147 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
                 const int row = m0 + (wm * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M) {
                     if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][r];
-                    else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[t][r], row, col);
+                    else gemm_store(g, row, col, gemm_epilogue(g, acc[t][r], row, col));
                 }
             }
     }
+}
+// 128 x (32 NT) form: the 4 waves stack along M (32 rows each) and every wave owns NT column tiles, so a k-step of 16 reads 2 + 2 NT LDS
+// fragments for 3 NT matrix instructions (NT = 3: 8 for 9, against 4 for 3 in k_conv_gemm_h<1>), a 96-column stage has no padded columns
+// (BN = 64 wastes a quarter of the matrix work at N = 96) and the activation tile is fetched once per 96 output columns instead of once per 64.
+// One K tile in flight and ~110 VGPRs / 36 KB of LDS keep 4 workgroups per CU -- the middle ground between k_conv_gemm_h<1> (8 per CU, the
+// L2 -> LDS traffic 2.3 x larger) and k_conv_gemm_h2<2, 3> (2 per CU, spills).  Reads pre-split operands as copies.
+template <int MR, int NT>
+__global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
+    constexpr int BM = 128 * MR, BN = 32 * NT, BK = 32, LD = 40;
+    constexpr int NA = BM * 8 / 256;
+    constexpr int NB = (BN * 4 + 255) / 256;
+    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
+    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
+    f32x16 acc[MR][NT];
+#pragma unroll
+    for (int t = 0; t < MR; t++)
+#pragma unroll
+        for (int u = 0; u < NT; u++)
+#pragma unroll
+            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
+    float4 ra[NA];
+    uint4 rh[NB], rl[NB];
+    int arow[NA];
+#pragma unroll
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
+    auto fetch = [&](int k0) {
+        const int j = k0 / g.cin, ci0 = k0 % g.cin;
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+            if (m0 + r < g.M) ra[i] = g.a_split ? load_a4_split_raw(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * kq)
+                                                : *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
+            if (e < BN * 4 && n0 + r < g.N) {
+                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
+                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
+            }
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < NA; i++) {
+            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            if (g.a_split) {
+                *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(ra[i].x, ra[i].y);
+                *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(ra[i].z, ra[i].w);
+                continue;
+            }
+            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+            h4v hi, lo;
+#pragma unroll
+            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
+            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+        }
+#pragma unroll
+        for (int i = 0; i < NB; i++) {
+            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
+        }
+    };
+    fetch(kbeg);
+    for (int k0 = kbeg; k0 < kend; k0 += BK) {
+        stash();
+        __syncthreads();
+        if (k0 + BK < kend) fetch(k0 + BK);
+#pragma unroll
+        for (int kk = 0; kk < BK; kk += 16) {
+            const int ko = kk + 8 * (lane >> 5);
+            if constexpr (MR == 1) {
+                const int ar = wave * 32 + (lane & 31);
+                const h8v ah = *reinterpret_cast<const h8v*>(&Ah[ar][ko]);
+                const h8v al = *reinterpret_cast<const h8v*>(&Al[ar][ko]);
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const h8v bh = *reinterpret_cast<const h8v*>(&Bh[u * 32 + (lane & 31)][ko]);
+                    const h8v bl = *reinterpret_cast<const h8v*>(&Bl[u * 32 + (lane & 31)][ko]);
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[0][u], 0, 0, 0);
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[0][u], 0, 0, 0);
+                    acc[0][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[0][u], 0, 0, 0);
+                }
+            } else {
+                h8v bh[NT], bl[NT];
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    bh[u] = *reinterpret_cast<const h8v*>(&Bh[u * 32 + (lane & 31)][ko]);
+                    bl[u] = *reinterpret_cast<const h8v*>(&Bl[u * 32 + (lane & 31)][ko]);
+                }
+#pragma unroll
+                for (int t = 0; t < MR; t++) {
+                    const int ar = (wave * MR + t) * 32 + (lane & 31);
+                    const h8v ah = *reinterpret_cast<const h8v*>(&Ah[ar][ko]);
+                    const h8v al = *reinterpret_cast<const h8v*>(&Al[ar][ko]);
+#pragma unroll
+                    for (int u = 0; u < NT; u++) {
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], acc[t][u], 0, 0, 0);
+                        acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[t][u], 0, 0, 0);
+                    }
+                    __builtin_amdgcn_sched_barrier(0); // keep one row tile's operands live at a time (the scheduler otherwise hoists every LDS read and spills)
+                }
+            }
+        }
+        __syncthreads();
+    }
+    // rows outermost: one row's addresses live at a time (columns outermost made the compiler keep every row's 64-bit addresses in
+    // registers: 256 VGPRs, one wave per SIMD).  One call per row tile: a `for t` loop is "too large to unroll" and turns acc[t] into a
+    // scratch array.
+    auto epilogue_rows = [&](const f32x16 (&a)[NT], int row0) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = row0 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+#pragma unroll
+                for (int u = 0; u < NT; u++) {
+                    const int col = n0 + u * 32 + (lane & 31);
+                    if (col < g.N) {
+                        if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = a[u][r];
+                        else gemm_store(g, row, col, gemm_epilogue(g, a[u][r], row, col));
+                    }
+                }
+            }
+        }
+    };
+    epilogue_rows(acc[0], m0 + wave * MR * 32);
+    if constexpr (MR > 1) epilogue_rows(acc[1], m0 + (wave * MR + 1) * 32);
+    static_assert(MR <= 2, "one epilogue call per row tile");
 }
 // Register-blocked form of the split-f16 GEMM for large M: the 4 waves of a workgroup stack along M and each wave owns MR x NT tiles of
 // 32 x 32 (workgroup tile (128 MR) x (32 NT); MR = 2, NT = 3 -> 256 x 96, and every channel count of the decoder is 96 * 2^k, so no column of
@@ -257,7 +430,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
     uint4 rh[2][NB], rl[2][NB];
     int arow[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + (mm / g.a_segT) * g.a_skip; }
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
     auto fetch = [&](int k0, float4* ra_, uint4* rh_, uint4* rl_) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
@@ -344,7 +517,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16
                 const int row = m0 + (wave * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
                 if (row < g.M) {
                     if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][u][r];
-                    else g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[t][u][r], row, col);
+                    else gemm_store(g, row, col, gemm_epilogue(g, acc[t][u][r], row, col));
                 }
             }
     }
@@ -374,7 +547,7 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
     const int rt = wave % NRT, cg = wave / NRT;
     const int m0 = blockIdx.x * BM;
     const int wrows = BM + 6 * g.dil;
-    const size_t base_row = (size_t)m0 + (size_t)(m0 / g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
+    const size_t base_row = (size_t)m0 + (size_t)seg_of(m0, g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
     // With the window in LDS only ONE workgroup (one wave per SIMD) fits a CU, so nothing but the wave's own loads in flight hides latency:
     // the weight tiles run DEPTH K tiles ahead in registers (K / 32 is a multiple of 3: K = 7 C, C = 96 or 192), and the window is fetched
     // with ALL its loads issued before the first conversion (a rolled loop paid one ~2 us HBM round trip per iteration: 34 us per workgroup).
@@ -459,7 +632,7 @@ __global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16*
 #pragma unroll
         for (int r = 0; r < 16; r++) {
             const int row = m0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) g.out[out_off(g, row, col)] = gemm_epilogue(g, acc[u][r], row, col);
+            if (row < g.M) gemm_store(g, row, col, gemm_epilogue(g, acc[u][r], row, col));
         }
     }
 }
@@ -479,7 +652,7 @@ __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const int row = (int)(i / g.N), col = (int)(i % g.N);
     float v = g.ws[i];
     for (int s = 1; s < ksplit; s++) v += g.ws[(size_t)s * g.M * g.N + i];
-    g.out[out_off(g, row, col)] = gemm_epilogue(g, v, row, col);
+    gemm_store(g, row, col, gemm_epilogue(g, v, row, col));
 }
 
 // Skinny GEMM for M <= 16 (transformer, ConvNeXt MLPs, conv_in, first transposed conv): weights are streamed exactly
@@ -509,7 +682,7 @@ __global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
             float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m < g.M && kk < kt) {
                 const int kg = k0 + kk, j = kg / g.cin, ci = kg % g.cin;
-                v = *reinterpret_cast<const float4*>(g.A + (size_t)(m + (m / g.a_segT) * g.a_skip + j * g.dil) * g.lda + ci);
+                v = load_a4(g, (size_t)(m + seg_of(m, g.a_segT) * g.a_skip + j * g.dil), ci);
             }
             *reinterpret_cast<float4*>(&As[m][kk]) = v;
         }
@@ -531,7 +704,7 @@ __global__ void __launch_bounds__(512) k_skinny_gemm(GemmArgs g) {
         for (int o = 32; o >= 1; o >>= 1) v += __shfl_xor(v, o);
         if (lane == m) mine = v;
     }
-    if (lane < MT && lane < g.M && n < g.N) g.out[out_off(g, lane, n)] = gemm_epilogue(g, mine, lane, n);
+    if (lane < MT && lane < g.M && n < g.N) gemm_store(g, lane, n, gemm_epilogue(g, mine, lane, n));
 }
 static const bool g_codec_f32 = [] { const char* e = std::getenv("Q3_CODEC_F32"); return e && e[0] == '1'; }(); // A/B switch
 static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const _Float16* wh = nullptr, const _Float16* wl = nullptr) {
@@ -558,7 +731,7 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     // in flight, with libm or the short sine in the epilogue: a 91 / 125 KB window leaves ONE workgroup (one wave per SIMD) per CU, and one wave
     // per SIMD cannot overlap its own LDS reads, matrix instructions, barriers and epilogue the way eight small workgroups overlap each other's.
     static const int win_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_WIN_MIN_WGS"); return e ? atoi(e) : 0; }(); // 0 = never
-    if (wh && !g_codec_f32 && win_min_wgs > 0 && g.cin == g.N && g.K == 7 * g.cin && g.dil <= 9 && (g.N == 96 || g.N == 192)) {
+    if (wh && !g_codec_f32 && !g.a_split && !g.o_split && win_min_wgs > 0 && g.cin == g.N && g.K == 7 * g.cin && g.dil <= 9 && (g.N == 96 || g.N == 192)) {
         const int bm = g.N == 96 ? 128 : 64;
         if (g.M % bm == 0 && (g.a_segT == SEG_NONE || g.a_segT % bm == 0) && g.M / bm >= win_min_wgs) {
             const size_t lds96 = conv7_win_lds<96, 128>(), lds192 = conv7_win_lds<192, 64>();
@@ -568,7 +741,7 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         }
     }
     static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 0; }(); // 0 = never
-    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
+    if (!small && wh && !g_codec_f32 && !g.a_split && !g.o_split && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
         (g.N / 96) * ((g.M + 255) / 256) >= 128) { // register-blocked 256 x 96 tiles, when they still make >= 128 workgroups before split-K
         const int t2 = (g.N / 96) * ((g.M + 255) / 256);
         static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }();
@@ -579,6 +752,14 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
             const size_t n = (size_t)g.M * g.N;
             hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
         }
+        return;
+    }
+    static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
+        static const int h3_nt6 = [] { const char* e = std::getenv("Q3_CODEC_H3_NT6"); return e ? atoi(e) : 0; }(); // workgroups from which N % 192 == 0 uses 192-column tiles
+        if (h3_nt6 > 0 && (g.N / 96) * ((g.M + 255) / 256) >= h3_nt6) // "NT6" knob reused: workgroups from which the 256-row tile is used
+            hipLaunchKernelGGL((k_conv_gemm_h3<2, 3>), dim3(g.N / 96, (g.M + 255) / 256, 1), dim3(256), 0, st, g, wh, wl);
+        else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
         return;
     }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
@@ -609,7 +790,7 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
 // Row maps: a batched extended buffer holds G segments of (H + T) rows; logical row r (= g*T + t) lives at physical row
 // r + (r / segT) * skip + off  (segT = T, skip = H, off = 0 for the "history first" view, off = H for the "current rows" view).
 struct RowMap { int segT, skip, off; };
-__device__ __forceinline__ size_t map_row(const RowMap& m, int r) { return (size_t)r + (size_t)(r / m.segT) * m.skip + m.off; }
+__device__ __forceinline__ size_t map_row(const RowMap& m, int r) { return (size_t)r + (size_t)(m.segT == SEG_NONE ? 0 : r / m.segT) * m.skip + m.off; }
 static RowMap plain_map() { return RowMap{SEG_NONE, 0, 0}; }
 
 __global__ void k_rvq_sum(const int64_t* __restrict__ codes, const float* const* __restrict__ cb, int n_q, int cb_size, int cb_dim,
@@ -734,13 +915,21 @@ __global__ void k_dwconv7(const float* __restrict__ in_ext, int C, const float* 
 }
 // y = x + inv_eb[c] * sin^2(x*ea[c]); src plain rows [T][C] -> dst rows through the map
 __global__ void k_snake(const float* __restrict__ src, float* __restrict__ dst, int C, const float* __restrict__ ea,
-                        const float* __restrict__ inv_eb, size_t n, RowMap dm) {
+                        const float* __restrict__ inv_eb, size_t n4, RowMap dm, int split) { // 4 channels per thread (C % 4 == 0)
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i >= n) return;
-    const int c = (int)(i % C), r = (int)(i / C);
-    const float v = src[i];
-    const float s = snake_sin(v * ea[c]);
-    dst[map_row(dm, r) * C + c] = v + inv_eb[c] * (s * s);
+    if (i >= n4) return;
+    const int c4 = C >> 2, c = (int)(i % c4) * 4, r = (int)(i / c4);
+    const float4 v = reinterpret_cast<const float4*>(src)[i];
+    const float4 a = *reinterpret_cast<const float4*>(ea + c), b = *reinterpret_cast<const float4*>(inv_eb + c);
+    const float s0 = snake_sin(v.x * a.x), s1 = snake_sin(v.y * a.y), s2 = snake_sin(v.z * a.z), s3 = snake_sin(v.w * a.w);
+    const float4 y = make_float4(v.x + b.x * (s0 * s0), v.y + b.y * (s1 * s1), v.z + b.z * (s2 * s2), v.w + b.w * (s3 * s3));
+    float* drow = dst + map_row(dm, r) * C;
+    if (!split) { *reinterpret_cast<float4*>(drow + c) = y; return; }
+    _Float16* row = reinterpret_cast<_Float16*>(drow); // split row: [C hi][C lo]
+    h4v_ hi, lo;
+    hi[0] = (_Float16)y.x; hi[1] = (_Float16)y.y; hi[2] = (_Float16)y.z; hi[3] = (_Float16)y.w;
+    lo[0] = (_Float16)(y.x - (float)hi[0]); lo[1] = (_Float16)(y.y - (float)hi[1]); lo[2] = (_Float16)(y.z - (float)hi[2]); lo[3] = (_Float16)(y.w - (float)hi[3]);
+    *reinterpret_cast<h4v_*>(row + c) = hi; *reinterpret_cast<h4v_*>(row + C + c) = lo;
 }
 __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ dst, size_t n, int C, RowMap dm) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -799,6 +988,7 @@ struct CodecDecoder::Impl {
     // per-stream state
     Ext z_ext, convin_ext, out_ext; std::vector<Ext> dw_ext, ct_ext, k_ext, v_ext; std::vector<std::vector<Ext>> ru_ext;
     std::vector<Ext*> all_ext;
+    bool presplit = false; // Q3_CODEC_PRESPLIT=1: SnakeBeta outputs feeding GEMMs are stored as hi / lo f16 planes (measured: no gain)
     std::vector<int> kv_len; std::vector<long long> n_seen;
     int gmax = 1; // streams decoded together in one pass
     struct Scratch { // one set per concurrency lane: independent decodes run on different HIP streams at the same time
@@ -876,8 +1066,10 @@ struct CodecDecoder::Impl {
     RowMap base_map(const Ext& e, int T) { return RowMap{T, e.H, 0}; }
     // out_rows_per_m: a transposed conv writes f consecutive C-wide rows per GEMM row (ldo = f*C); skip stays H*C floats per segment
     void run_conv(hipStream_t st, const ConvW& c, Loc A, int lda, int M, Loc out, int ldo, int out_C, int epi = EPI_NONE,
-                  Loc res = Loc{nullptr, SEG_NONE, 0}, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr) {
+                  Loc res = Loc{nullptr, SEG_NONE, 0}, int ldr = 0, const float* scale = nullptr, const Snake* sn = nullptr, bool a_split = false,
+                  bool o_split = false) {
         GemmArgs g{};
+        g.a_split = a_split ? 1 : 0; g.o_split = o_split ? 1 : 0;
         g.A = A.p; g.lda = lda; g.cin = c.cin; g.dil = c.dil; g.W = c.w.p; g.bias = c.b.n ? c.b.p : nullptr; g.out = out.p; g.ldo = ldo;
         g.M = M; g.N = c.N; g.K = c.K; g.epi = epi; g.res = res.p; g.ldr = ldr; g.scale = scale;
         g.a_segT = A.segT; g.a_skip = (int)A.skip_rows;
@@ -900,9 +1092,10 @@ struct CodecDecoder::Impl {
         hipLaunchKernelGGL(k_hist_all, dim3((unsigned)((mx + 255) / 256), G, table.n), dim3(256), 0, st, table, meta, save ? 1 : 0);
     }
 
-    void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int rows, RowMap dm) {
-        const size_t n = (size_t)rows * s.C;
-        hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n, dm);
+    void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int rows, RowMap dm, bool split = false) {
+        Q3_CHECK(s.C % 4 == 0, "SnakeBeta channel count must be a multiple of 4");
+        const size_t n = (size_t)rows * (s.C / 4);
+        hipLaunchKernelGGL(k_snake, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, src, dst, s.C, s.ea.p, s.inv_eb.p, n, dm, split ? 1 : 0);
     }
     void copy_rows(hipStream_t st, const float* src, float* dst, int rows, int C, RowMap dm) {
         const size_t n = (size_t)rows * C;
@@ -913,6 +1106,8 @@ struct CodecDecoder::Impl {
 CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes, int max_group) : impl_(new Impl()) {
     init_codec_kernel_attributes();
     Impl& m = *impl_;
+    if (const char* e = std::getenv("Q3_CODEC_PRESPLIT")) m.presplit = !(e[0] == '0');
+    if (g_codec_f32) m.presplit = false; // the f32-only A/B mode keeps full f32 operands
     Gguf g(path);
     m.n_streams = n_streams; m.max_frames = max_frames; m.gmax = max_group > 0 ? max_group : 1;
     m.n_q = (int)g.kv_int("codec.n_codebooks", 16); m.cb_size = (int)g.kv_int("codec.codebook_size", 2048);
@@ -1231,17 +1426,17 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
     for (int b = 0; b < m.n_dec; b++) {
         auto& B = m.blk[b];
         Ext& ce = m.ct_ext[b];
-        m.snake(st, B.snake, d, m.work(ce), G * T, m.cur_map(ce, T));
+        m.snake(st, B.snake, d, m.work(ce), G * T, m.cur_map(ce, T), m.presplit);
         float* y = (d == m.S->t1.p) ? m.S->t2.p : m.S->t1.p; // [G*T*r][co]
-        m.run_conv(st, B.ct, m.ext_base(ce, T), B.cin, G * T, m.plain(y), B.rate * B.cout, B.cout);
+        m.run_conv(st, B.ct, m.ext_base(ce, T), B.cin, G * T, m.plain(y), B.rate * B.cout, B.cout, EPI_NONE, Impl::Loc{nullptr, SEG_NONE, 0}, 0, nullptr, nullptr, m.presplit);
         T *= B.rate;
         for (int u = 0; u < 3; u++) {
             Ext& re = m.ru_ext[b][u];
             auto& R = B.ru[u];
-            m.snake(st, R.s1, y, m.work(re), G * T, m.cur_map(re, T));
+            m.snake(st, R.s1, y, m.work(re), G * T, m.cur_map(re, T), m.presplit);
             float* c1o = d; // the block input buffer is free now: reuse as scratch [G*T][co]
-            m.run_conv(st, R.c1, m.ext_base(re, T), B.cout, G * T, m.plain(c1o), B.cout, B.cout, EPI_SNAKE, Impl::Loc{nullptr, SEG_NONE, 0}, 0, nullptr, &R.s2); // conv1 + snake2 fused
-            m.run_conv(st, R.c2, m.plain(c1o), B.cout, G * T, m.plain(y), B.cout, B.cout, EPI_RES, m.plain(y), B.cout);
+            m.run_conv(st, R.c1, m.ext_base(re, T), B.cout, G * T, m.plain(c1o), B.cout, B.cout, EPI_SNAKE, Impl::Loc{nullptr, SEG_NONE, 0}, 0, nullptr, &R.s2, m.presplit, m.presplit); // conv1 + snake2 fused
+            m.run_conv(st, R.c2, m.plain(c1o), B.cout, G * T, m.plain(y), B.cout, B.cout, EPI_RES, m.plain(y), B.cout, nullptr, nullptr, m.presplit);
         }
         d = y;
     }
