@@ -200,7 +200,7 @@ def load_traffic(kernel_key):
         tab = json.load(open(path))
     except (OSError, ValueError):
         return None
-    ent = tab.get(kernel_key)
+    ent = tab.get(kernel_key) or next((v for k, v in tab.items() if k.startswith(kernel_key.rstrip(">"))), None)  # template arguments may follow
     return float(ent["read_bytes"] + ent.get("write_bytes", 0.0)) if ent else None
 
 
@@ -405,7 +405,9 @@ def main(argv=None):
         gu_bpl = si["gu_bytes"] / max(si["gu_launches"], 1)
         ntok = args.batch
         if args.batch == 1:
-            kname, kkey = "q3::k_gateup_swiglu<1, 8> (talker: norm + gate/up GEMV + SwiGLU + quant)", "k_gateup_swiglu<1, 8>"
+            kq = args.quant == "q5_k_m"
+            kname = "q3::k_gateup_swiglu<1, 8, %s> (talker: norm + gate/up GEMV + SwiGLU + quant%s)" % ("true" if kq else "false", ", packed K-quant planes" if kq else "")
+            kkey = "k_gateup_swiglu<1, 8, true>" if kq else "k_gateup_swiglu<1, 8>"
         elif is_float:
             kname, kkey = "q3::k_gateup_float_mfma16 / k_gemm_float_mfma (talker gate/up, K = 1 f32 MFMA chains)", "k_gateup_float"
         else:

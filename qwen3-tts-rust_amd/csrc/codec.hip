@@ -755,7 +755,8 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         return;
     }
     static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
-    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
+    static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
         static const int h3_nt6 = [] { const char* e = std::getenv("Q3_CODEC_H3_NT6"); return e ? atoi(e) : 0; }(); // workgroups from which N % 192 == 0 uses 192-column tiles
         if (h3_nt6 > 0 && (g.N / 96) * ((g.M + 255) / 256) >= h3_nt6) // "NT6" knob reused: workgroups from which the 256-row tile is used
             hipLaunchKernelGGL((k_conv_gemm_h3<2, 3>), dim3(g.N / 96, (g.M + 255) / 256, 1), dim3(256), 0, st, g, wh, wl);

@@ -15,12 +15,21 @@ struct Q8Mat {
     int N = 0;      // logical rows
     int Npad = 0;   // rows padded to 32
     int K = 0;
-    // K-quant support (Q5_K / Q6_K rows expanded to int8 planes at load, exact): per-row-group ggml type and a 16-B metadata
-    // vector per (row, segment): Q5_K = {sc[8], m[8]} u8 with d,dmin in sc[0..1]; Q6_K = 16 i8 sub-block scales with d in sc[0].
-    const uint8_t* rg_type = nullptr;   // [Npad/32], null => all Q8_0
+    // K-quant rows (Q5_K / Q6_K) stay PACKED in HBM and are unpacked in registers in front of the int8 dot products.  A matrix with K-quant
+    // row groups carries the ggml type and the byte offset (in 16-B units) of every 32-row group; per (row group, 256-segment):
+    //   nibble plane   [8 blocks][2 halves][32 rows][8 B]   low 4 bits; byte b of word w holds weights 8w+b (low nibble) and 8w+4+b (high nibble) of the half
+    //   high plane     Q5_K: [32 rows][8 blocks][4 B]        bit 8b+J of the word = bit 4 of weight 4J+b of the block
+    //                  Q6_K: [32 rows][8 blocks][2][4 B]     the same for bit 4 (word 0) and bit 5 (word 1); values are stored +32 (unsigned 6 bit)
+    // = 0.625 / 0.75 B per weight (+ 0.125 of scales and metadata), against 1.125 for the int8 planes round 1 expanded them to.
+    // Metadata: one 16-B vector per (row, segment): Q5_K = {sc[8], m[8]} u8 with d,dmin in sc[0..1]; Q6_K = 16 i8 sub-block scales with d in sc[0].
+    const uint8_t* rg_type = nullptr;   // [Npad/32], null => all Q8_0 (uniform 1-KiB tiles)
+    const uint32_t* rg_off = nullptr;   // [Npad/32] offset of the row group's quants from qs in 16-B units (K-quant matrices only)
     const uint8_t* meta = nullptr;      // [N/32][K/256][32 rows][16 B]
-    size_t bytes() const { return (size_t)Npad * K + (size_t)Npad * (K / 32) * 2; }
+    size_t qbytes = 0;                  // bytes of the quant planes as stored (0 => Npad*K)
+    size_t bytes() const { return (qbytes ? qbytes : (size_t)Npad * K) + (size_t)Npad * (K / 32) * 2 + (meta ? (size_t)Npad * (K / 256) * 16 : 0); }
 };
+// bytes of one 32-row group of K columns in HBM, by ggml type (8 = Q8_0, 13 = Q5_K, 14 = Q6_K)
+inline size_t q3_rowgroup_bytes(int type, int K) { return type == 13 ? (size_t)(K / 256) * 5120 : type == 14 ? (size_t)(K / 256) * 6144 : (size_t)(K / 32) * 1024; }
 
 // Per-token routing for batched steps (one entry per token row of the activation matrix)
 struct TokMeta {

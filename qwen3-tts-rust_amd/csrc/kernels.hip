@@ -12,6 +12,7 @@
 #include "q3_common.h"
 #include "../../include/q3tts_spec.h"
 #include "kdev.h"
+#include "wslice.h"
 
 namespace q3 {
 
@@ -154,7 +155,7 @@ static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
 template <int LPR, int MT>
 __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                  const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride, int ntok) {
-    constexpr int R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    constexpr int R = 64 / LPR;
     __shared__ float red[8][R * MT];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
@@ -168,59 +169,15 @@ __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, c
     if (active) {
         int row = row0 + blockIdx.x * R + r;
         if (row > w.Npad - 1) row = w.Npad - 1;
-        const int rg = row >> 5, r32 = row & 31;
-        const int wt = w.rg_type ? w.rg_type[rg] : Q3_T_Q8_0;
-        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-        uint4 wv[NLD];
-#pragma unroll
-        for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
-        const size_t vidx = ((size_t)rg * nseg + seg) * 32 + r32;
-        const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + vidx * 8);
-        uint4 mv = make_uint4(0, 0, 0, 0);
-        if (wt != Q3_T_Q8_0) mv = *reinterpret_cast<const uint4*>(w.meta + vidx * 16);
-        const float d0 = h2f(half_of(dwv, 0)), d1 = h2f(half_of(dwv, 1)); // K-quants: d, dmin
-        auto mbyte = [&](int k) -> int { const uint32_t ww = k < 4 ? mv.x : k < 8 ? mv.y : k < 12 ? mv.z : mv.w; return (int)((ww >> (8 * (k & 3))) & 0xFFu); };
+        WSlice<LPR, true> ws;
+        ws.load(w, row >> 5, row & 31, seg, half, bil);
+        ws.finish(half);
 #pragma unroll
         for (int m = 0; m < MT; m++) {
             int tok = tok0 + m;
             if (tok > ntok - 1) tok = ntok - 1;
-            const int8_t* xp = xq + (size_t)tok * w.K + seg * 256;
             const uint4 dxv = *reinterpret_cast<const uint4*>(xd + (size_t)tok * nb + seg * 8);
-#pragma unroll
-            for (int i = 0; i < NLD; i++) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(xp + (i * BPL + bil) * 32 + half * 16);
-                int isum = dot16(wv[i], xv);
-                int xsum = 0;
-                if (wt == Q3_T_Q5_K) {
-                    const uint4 ones = make_uint4(0x01010101u, 0x01010101u, 0x01010101u, 0x01010101u);
-                    xsum = dot16(ones, xv);
-                    xsum += xor_lane<R>(xsum);
-                } else if (wt == Q3_T_Q6_K) {
-                    const int bsel = i * BPL + bil; // block index inside the segment of THIS lane's data
-                    isum *= (int)(int8_t)mbyte(2 * bsel + half);
-                }
-                isum += xor_lane<R>(isum);
-#pragma unroll
-                for (int j = 0; j < BPL; j++) {
-                    const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
-                    const int xsj = (BPL == 1) ? xsum : __shfl(xsum, r + 2 * j * R);
-                    const int b = i * BPL + j;
-                    const float dxf = h2f(half_of(dxv, b));
-                    if (wt == Q3_T_Q8_0) {
-                        const float sc = h2f(half_of(dwv, b)) * dxf;
-                        acc[m] = q3_fmaf((float)isj, sc, acc[m]);
-                    } else if (wt == Q3_T_Q5_K) {
-                        const int i1 = mbyte(b) * isj, i2 = mbyte(8 + b) * xsj;
-                        const float a = d0 * (float)i1;
-                        const float a2 = d1 * (float)i2;
-                        const float diff = a - a2;
-                        acc[m] = q3_fmaf(diff, dxf, acc[m]);
-                    } else {
-                        const float a = d0 * (float)isj;
-                        acc[m] = q3_fmaf(a, dxf, acc[m]);
-                    }
-                }
-            }
+            acc[m] = ws.chain(acc[m], xq + (size_t)tok * w.K + seg * 256, dxv, r, half, bil);
         }
         if (q == 0) {
 #pragma unroll

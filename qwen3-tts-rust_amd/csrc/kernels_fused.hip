@@ -11,6 +11,7 @@
 // Arithmetic is include/q3tts_spec.h's, bit-identical to the unfused kernels and to oracle/.
 #include "kernels.h"
 #include "kdev.h"
+#include "wslice.h"
 #include <cstdlib>
 #include "q3_common.h"
 
@@ -150,10 +151,10 @@ void launch_rmsnorm_quant_wg(hipStream_t st, const NormPro& a, int d, int8_t* xq
 // ===================================================================================================
 // A: norm prologue + GEMV (K = d <= 2048, one super-segment).  EPI 0: store f32; EPI 1: atomic argmax.
 // ===================================================================================================
-template <int LPR, int MT, int EPI>
+template <int LPR, int MT, int EPI, bool KQ>
 __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nrows, NormPro a, float* __restrict__ out,
                                                       int out_stride, int ntok, ArgmaxEpi am) {
-    constexpr int R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    constexpr int R = 64 / LPR;
     __shared__ float red[8][R * MT];
     __shared__ __attribute__((aligned(16))) int8_t xq_s[MT][2048];
     __shared__ __attribute__((aligned(16))) uint16_t xd_s[MT][64];
@@ -161,42 +162,26 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
     __shared__ float scal_s[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
-    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int nseg = w.K >> 8;
     const int seg = wave; // single super-segment
     const int tok0 = blockIdx.z * MT;
     int row = row0 + blockIdx.x * R + r;
     if (row > w.Npad - 1) row = w.Npad - 1;
-    const int rg = row >> 5, r32 = row & 31;
     // weight stream first: independent of the activations, flies while the prologue runs
-    const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-    uint4 wv[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
-    const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+    WSlice<LPR, KQ> ws;
+    ws.load(w, row >> 5, row & 31, seg, half, bil);
     for (int m = 0; m < MT; m++) { // (nwaves == K/256 by construction of the launch)
         const int tok = tok0 + m;
         norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
     }
     __syncthreads();
+    ws.finish(half);
     float acc[MT];
 #pragma unroll
     for (int m = 0; m < MT; m++) {
-        acc[m] = 0.0f;
         const int mm = (tok0 + m < ntok) ? m : 0; // clamp like the unfused kernel (result unused)
         const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + (i * BPL + bil) * 32 + half * 16]);
-            int isum = dot16(wv[i], xv);
-            isum += xor_lane<R>(isum);
-#pragma unroll
-            for (int j = 0; j < BPL; j++) {
-                const int isj = (BPL == 1) ? isum : __shfl(isum, r + 2 * j * R);
-                const int b = i * BPL + j;
-                const float sc = h2f(half_of(dwv, b)) * h2f(half_of(dxv, b));
-                acc[m] = q3_fmaf((float)isj, sc, acc[m]);
-            }
-        }
+        acc[m] = ws.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, bil);
     }
     if (q == 0) {
 #pragma unroll
@@ -232,7 +217,8 @@ static void gemv_norm_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows
     constexpr int R = 64 / LPR;
     const int nseg = w.K >> 8;
     dim3 grid((nrows + R - 1) / R, 1, (ntok + MT - 1) / MT);
-    hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
+    if (w.rg_type) hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI, true>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
+    else hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI, false>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
 }
 template <int LPR, int EPI>
 static void gemv_norm_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride, int ntok,
@@ -257,7 +243,7 @@ void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, co
 // ===================================================================================================
 // NSEG (waves = 256-element segments of K; 8 = the talker's K = 2048) is a template parameter only so that profiles list the talker's
 // and the predictor's launches as different kernels: bench.py's roofline line is about k_gateup_swiglu<1, 8>.
-template <int MT, int NSEG>
+template <int MT, int NSEG, bool KQ>
 __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, NormPro a, int8_t* __restrict__ aq,
                                                              uint16_t* __restrict__ ad, int ntok) {
     __shared__ float red[8][2][32 * MT];
@@ -267,35 +253,47 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
     __shared__ float scal_s[1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
-    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int nseg = w.K >> 8;
     const int seg = wave;
     const int tok0 = blockIdx.z * MT;
     const int rgG = blockIdx.x, rgU = (ff >> 5) + blockIdx.x;
-    const uint8_t* baseG = w.qs + ((size_t)rgG * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
-    const uint8_t* baseU = w.qs + ((size_t)rgU * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
-    uint4 wg[8], wu[8];
+    WSlice<2, KQ> wsg, wsu;
+    if (!KQ) { // the two weight streams interleaved, as the Q8_0 kernel always issued them
+        const int nb = w.K >> 5;
+        const uint8_t* baseG = w.qs + ((size_t)rgG * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
+        const uint8_t* baseU = w.qs + ((size_t)rgU * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
 #pragma unroll
-    for (int i = 0; i < 8; i++) { wg[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wu[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
-    const uint4 dg = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
-    const uint4 du = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
+        for (int i = 0; i < 8; i++) { wsg.wv[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wsu.wv[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
+        wsg.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
+        wsu.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
+    } else {
+        wsg.load(w, rgG, r, seg, half, 0);
+        wsu.load(w, rgU, r, seg, half, 0);
+    }
     for (int m = 0; m < MT; m++) {
         const int tok = tok0 + m;
         norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
     }
     __syncthreads();
+    wsg.finish(half); wsu.finish(half);
 #pragma unroll
     for (int m = 0; m < MT; m++) {
         const int mm = (tok0 + m < ntok) ? m : 0;
         const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
         float ag = 0.0f, au = 0.0f;
+        if (!KQ) {
 #pragma unroll
-        for (int i = 0; i < 8; i++) {
-            const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
-            int ig = dot16(wg[i], xv), iu = dot16(wu[i], xv);
-            ig += xor_lane<32>(ig); iu += xor_lane<32>(iu);
-            const float dx = h2f(half_of(dxv, i));
-            ag = q3_fmaf((float)ig, h2f(half_of(dg, i)) * dx, ag);
-            au = q3_fmaf((float)iu, h2f(half_of(du, i)) * dx, au);
+            for (int i = 0; i < 8; i++) {
+                const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
+                int ig = dot16(wsg.wv[i], xv), iu = dot16(wsu.wv[i], xv);
+                ig += xor_lane<32>(ig); iu += xor_lane<32>(iu);
+                const float dx = h2f(half_of(dxv, i));
+                ag = q3_fmaf((float)ig, h2f(half_of(wsg.dwv, i)) * dx, ag);
+                au = q3_fmaf((float)iu, h2f(half_of(wsu.dwv, i)) * dx, au);
+            }
+        } else {
+            ag = wsg.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
+            au = wsu.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
         }
         if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
     }
@@ -320,7 +318,8 @@ void launch_gateup_swiglu(hipStream_t st, const Q8Mat& w, int ff, const NormPro&
     const int nseg = w.K >> 8;
     const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : 4;
     dim3 grid(ff / 32, 1, (ntok + mt - 1) / mt);
-#define Q3_GU(MTV, NS) hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok)
+#define Q3_GU(MTV, NS) do { if (w.rg_type) hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS, true>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok); \
+                            else hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS, false>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok); } while (0)
 #define Q3_GU_NS(NS) do { if (mt == 1) Q3_GU(1, NS); else if (mt == 2) Q3_GU(2, NS); else Q3_GU(4, NS); } while (0)
     switch (nseg) {
         case 1: Q3_GU_NS(1); break; case 2: Q3_GU_NS(2); break; case 3: Q3_GU_NS(3); break; case 4: Q3_GU_NS(4); break;
@@ -550,13 +549,13 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
 // cross-wave dependency.  Every workgroup repeats the (tiny) attention; only workgroup 0 appends K/V to the cache.
 // Requires n = slot+1 <= 64, n_head*128 == 2048 handled as 8 segments, grp == 2.
 // ===================================================================================================
-template <int MT>
+template <int MT, bool KQ>
 __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const float* __restrict__ qkv, int qkv_stride, int n_head,
                                                     int n_kv, const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w,
                                                     float eps, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
                                                     int n_ctx, const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv, int layer,
                                                     float* __restrict__ out, int out_stride, int ntok) {
-    constexpr int LPR = 8, R = 64 / LPR, BPL = LPR / 2, NLD = 8 / BPL;
+    constexpr int LPR = 8, R = 64 / LPR;
     __shared__ float red[8][R * MT];
     __shared__ __attribute__((aligned(16))) float q_s[8][2][128];
     __shared__ __attribute__((aligned(16))) uint16_t kcur_s[8][128];
@@ -566,16 +565,12 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
     __shared__ __attribute__((aligned(16))) uint16_t xd_s[8][8];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
-    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int nseg = w.K >> 8;
     const int seg = wave, kvh = wave;
     int row = blockIdx.x * R + r;
     if (row > w.Npad - 1) row = w.Npad - 1;
-    const int rg = row >> 5, r32 = row & 31;
-    const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-    uint4 wv[NLD];
-#pragma unroll
-    for (int i = 0; i < NLD; i++) wv[i] = *reinterpret_cast<const uint4*>(base + (size_t)(i * BPL + bil) * 1024);
-    const uint4 dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+    WSlice<LPR, KQ> ws;
+    ws.load(w, row >> 5, row & 31, seg, half, bil);
     const float scale = 0.08838834764831845f;
     const int jj = lane >> 4, dc = lane & 15;
     float acc[MT];
@@ -710,19 +705,8 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
         __builtin_amdgcn_wave_barrier();
         // ---- this wave's o-proj segment (spec S3 block chain) ----
         const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[wave][0]);
-#pragma unroll
-        for (int i = 0; i < NLD; i++) {
-            const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[wave][(i * BPL + bil) * 32 + half * 16]);
-            int isum = dot16(wv[i], xv);
-            isum += xor_lane<R>(isum);
-#pragma unroll
-            for (int j = 0; j < BPL; j++) {
-                const int isj = __shfl(isum, r + 2 * j * R);
-                const int b = i * BPL + j;
-                const float sc3 = h2f(half_of(dwv, b)) * h2f(half_of(dxv, b));
-                acc[m] = q3_fmaf((float)isj, sc3, acc[m]);
-            }
-        }
+        if (m == 0) ws.finish(half); // first use: the weight words have been in flight since the top of the kernel
+        acc[m] = ws.chain(acc[m], &xq_s[wave][0], dxv, r, half, bil);
         __builtin_amdgcn_wave_barrier();
     }
     if (q == 0) {
@@ -742,14 +726,12 @@ void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* 
                        const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                        const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok) {
     dim3 grid((nrows + 7) / 8);
-    if (ntok == 1) hipLaunchKernelGGL((k_oproj_attn<1>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps,
-                                      rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok);
-    else if (ntok == 2) hipLaunchKernelGGL((k_oproj_attn<2>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps,
-                                           rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok);
-    else if (ntok <= 4) hipLaunchKernelGGL((k_oproj_attn<4>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps,
-                                           rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok);
-    else hipLaunchKernelGGL((k_oproj_attn<8>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps,
-                            rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok);
+#define Q3_OA(MTV, KQV) hipLaunchKernelGGL((k_oproj_attn<MTV, KQV>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, \
+                                           rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok)
+#define Q3_OA_MT(KQV) do { if (ntok == 1) Q3_OA(1, KQV); else if (ntok == 2) Q3_OA(2, KQV); else if (ntok <= 4) Q3_OA(4, KQV); else Q3_OA(8, KQV); } while (0)
+    if (wo.rg_type) Q3_OA_MT(true); else Q3_OA_MT(false);
+#undef Q3_OA_MT
+#undef Q3_OA
 }
 
 // ===================================================================================================

@@ -7,7 +7,7 @@ namespace q3 {
 
 // ---- load-time repack: GGUF Q8_0 rows ([n][K/32]{f16 d; i8 qs[32]}) -> Q8Mat tiles (kernels.h) ----
 __global__ void k_repack_q8(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs,
-                            uint16_t* __restrict__ sc) {
+                            uint16_t* __restrict__ sc, int sc_row_extra) { // quants go to row row_off + r of qs, scales to row row_off + sc_row_extra + r
     const int nb = K >> 5, nseg = K >> 8;
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (size_t)n * nb) return;
@@ -16,15 +16,16 @@ __global__ void k_repack_q8(const uint8_t* __restrict__ raw, int n, int K, int r
     const int row = row_off + r, rg = row >> 5, r32 = row & 31;
     uint16_t d;
     memcpy(&d, src, 2);
-    sc[(((size_t)rg * nseg + (b >> 3)) * 32 + r32) * 8 + (b & 7)] = d;
+    const int srow = row + sc_row_extra;
+    sc[(((size_t)(srow >> 5) * nseg + (b >> 3)) * 32 + (srow & 31)) * 8 + (b & 7)] = d;
     uint8_t* dst = qs + ((size_t)rg * nb + b) * 1024 + r32 * 16;
     for (int i = 0; i < 16; i++) { dst[i] = src[2 + i]; dst[512 + i] = src[18 + i]; }
 }
 
-// Q5_K super-block {f16 d, dmin; u8 scales[12]; u8 qh[32]; u8 qs[128]} -> int8 plane (q in 0..31) + {d,dmin} + {sc[8], m[8]}
-__global__ void k_repack_q5k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, uint16_t* __restrict__ sc,
-                             uint8_t* __restrict__ meta) {
-    const int nb = K >> 5, nseg = K >> 8;
+// Q5_K super-block {f16 d, dmin; u8 scales[12]; u8 qh[32]; u8 qs[128]} -> packed planes (kernels.h) + {d,dmin} + {sc[8], m[8]}
+__global__ void k_repack_q5k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, const uint32_t* __restrict__ rg_off,
+                             uint16_t* __restrict__ sc, uint8_t* __restrict__ meta) {
+    const int nseg = K >> 8;
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (size_t)n * nseg) return;
     const int r = (int)(id / nseg), s = (int)(id % nseg);
@@ -35,24 +36,29 @@ __global__ void k_repack_q5k(const uint8_t* __restrict__ raw, int n, int K, int 
     memcpy(&d, blk, 2); memcpy(&dm, blk + 2, 2);
     for (int i = 0; i < 8; i++) sc[vidx * 8 + i] = i == 0 ? d : i == 1 ? dm : 0;
     const uint8_t *scales = blk + 4, *qh = blk + 16, *ql = blk + 48;
+    uint8_t* base = qs + (size_t)rg_off[rg] * 16 + (size_t)s * 5120;
     for (int j = 0; j < 8; j++) {
         int scv, mv;
         if (j < 4) { scv = scales[j] & 63; mv = scales[j + 4] & 63; }
         else { scv = (scales[j + 4] & 0xF) | ((scales[j - 4] >> 6) << 4); mv = (scales[j + 4] >> 4) | ((scales[j] >> 6) << 4); }
         meta[vidx * 16 + j] = (uint8_t)scv; meta[vidx * 16 + 8 + j] = (uint8_t)mv;
         const int jj = j >> 1, hi = j & 1;
-        uint8_t* dst = qs + ((size_t)rg * nb + (size_t)s * 8 + j) * 1024 + r32 * 16;
+        uint8_t q[32];
+        uint32_t H = 0;
         for (int l = 0; l < 32; l++) {
-            const int nib = hi ? (ql[32 * jj + l] >> 4) : (ql[32 * jj + l] & 0xF);
-            const int hb = (qh[l] >> (2 * jj + hi)) & 1;
-            dst[(l >> 4) * 512 + (l & 15)] = (uint8_t)(nib + 16 * hb);
+            q[l] = (uint8_t)(hi ? (ql[32 * jj + l] >> 4) : (ql[32 * jj + l] & 0xF));
+            H |= (uint32_t)((qh[l] >> (2 * jj + hi)) & 1) << (8 * (l & 3) + (l >> 2));
         }
+        for (int h = 0; h < 2; h++)
+            for (int w = 0; w < 2; w++)
+                for (int bb = 0; bb < 4; bb++) base[j * 512 + h * 256 + r32 * 8 + w * 4 + bb] = (uint8_t)(q[16 * h + 8 * w + bb] | (q[16 * h + 8 * w + 4 + bb] << 4));
+        memcpy(base + 4096 + r32 * 32 + j * 4, &H, 4);
     }
 }
-// Q6_K super-block {u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d} -> int8 plane (q-32) + d + 16 sub-block scales
-__global__ void k_repack_q6k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, uint16_t* __restrict__ sc,
-                             uint8_t* __restrict__ meta) {
-    const int nb = K >> 5, nseg = K >> 8;
+// Q6_K super-block {u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d} -> packed planes (values kept +32, unsigned 6 bit) + d + 16 sub-block scales
+__global__ void k_repack_q6k(const uint8_t* __restrict__ raw, int n, int K, int row_off, uint8_t* __restrict__ qs, const uint32_t* __restrict__ rg_off,
+                             uint16_t* __restrict__ sc, uint8_t* __restrict__ meta) {
+    const int nseg = K >> 8;
     const size_t id = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (id >= (size_t)n * nseg) return;
     const int r = (int)(id / nseg), s = (int)(id % nseg);
@@ -63,21 +69,30 @@ __global__ void k_repack_q6k(const uint8_t* __restrict__ raw, int n, int K, int 
     memcpy(&d, blk + 208, 2);
     for (int i = 0; i < 8; i++) sc[vidx * 8 + i] = i == 0 ? d : 0;
     for (int i = 0; i < 16; i++) meta[vidx * 16 + i] = blk[192 + i];
+    uint8_t* base = qs + (size_t)rg_off[rg] * 16 + (size_t)s * 6144;
     for (int j = 0; j < 8; j++) {
         const int half = j >> 2, grp = j & 3;
         const uint8_t* L = blk + 64 * half;
-        const uint8_t* H = blk + 128 + 32 * half;
-        uint8_t* dst = qs + ((size_t)rg * nb + (size_t)s * 8 + j) * 1024 + r32 * 16;
+        const uint8_t* Hq = blk + 128 + 32 * half;
+        uint8_t q[32];
+        uint32_t H0 = 0, H1 = 0;
         for (int l = 0; l < 32; l++) {
-            int q;
+            int lo, hb;
             switch (grp) {
-                case 0: q = (L[l] & 0xF) | (((H[l] >> 0) & 3) << 4); break;
-                case 1: q = (L[l + 32] & 0xF) | (((H[l] >> 2) & 3) << 4); break;
-                case 2: q = (L[l] >> 4) | (((H[l] >> 4) & 3) << 4); break;
-                default: q = (L[l + 32] >> 4) | (((H[l] >> 6) & 3) << 4); break;
+                case 0: lo = L[l] & 0xF; hb = (Hq[l] >> 0) & 3; break;
+                case 1: lo = L[l + 32] & 0xF; hb = (Hq[l] >> 2) & 3; break;
+                case 2: lo = L[l] >> 4; hb = (Hq[l] >> 4) & 3; break;
+                default: lo = L[l + 32] >> 4; hb = (Hq[l] >> 6) & 3; break;
             }
-            dst[(l >> 4) * 512 + (l & 15)] = (uint8_t)(int8_t)(q - 32);
+            q[l] = (uint8_t)lo;
+            H0 |= (uint32_t)(hb & 1) << (8 * (l & 3) + (l >> 2));
+            H1 |= (uint32_t)(hb >> 1) << (8 * (l & 3) + (l >> 2));
         }
+        for (int h = 0; h < 2; h++)
+            for (int w = 0; w < 2; w++)
+                for (int bb = 0; bb < 4; bb++) base[j * 512 + h * 256 + r32 * 8 + w * 4 + bb] = (uint8_t)(q[16 * h + 8 * w + bb] | (q[16 * h + 8 * w + 4 + bb] << 4));
+        memcpy(base + 4096 + r32 * 64 + j * 8, &H0, 4);
+        memcpy(base + 4096 + r32 * 64 + j * 8 + 4, &H1, 4);
     }
 }
 
@@ -95,49 +110,75 @@ Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& stora
     raw.upload((const uint8_t*)raw_q8_0, raw_bytes);
     const size_t nblk = (size_t)n * (k / 32);
     hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, n, k, 0, storage.p,
-                       reinterpret_cast<uint16_t*>(storage.p + qs_bytes));
+                       reinterpret_cast<uint16_t*>(storage.p + qs_bytes), 0);
     Q3_HIP(hipDeviceSynchronize());
     return m;
 }
 
-Q8Mat Transformer::make_mat(int N, int K) {
+Q8Mat Transformer::make_mat(const Gguf& g, const std::vector<std::pair<std::string, int>>& rows, int N, int K) {
     Q3_CHECK(K % 256 == 0, "K must be a multiple of 256");
     Q8Mat m;
     m.N = N; m.Npad = (N + 31) & ~31; m.K = K;
-    const size_t qs_bytes = (size_t)m.Npad * K, sc_bytes = (size_t)m.Npad * (K / 32) * 2;
-    const size_t meta_bytes = (size_t)m.Npad * (K / 256) * 16, ty_bytes = (size_t)((m.Npad / 32 + 15) & ~15);
-    blobs_.emplace_back(qs_bytes + sc_bytes + meta_bytes + ty_bytes);
+    const int nrg = m.Npad / 32;
+    // the tensors of the fused matrix decide the storage of every 32-row group (Q8_0 tiles or packed K-quant planes)
+    std::vector<uint8_t> types((size_t)nrg, (uint8_t)Q3_T_Q8_0);
+    bool kq = false;
+    for (auto& r : rows) {
+        const GgufTensor& t = g.need(r.first);
+        if (t.type != Q3_T_Q8_0 && t.type != Q3_T_Q5_K && t.type != Q3_T_Q6_K)
+            throw Error("tensor " + r.first + ": ggml type " + std::to_string(t.type) + " is not supported by the HIP path (Q8_0, Q5_K, Q6_K)");
+        Q3_CHECK(r.second % 32 == 0 && t.ne[1] % 32 == 0 && r.second + t.ne[1] <= m.Npad, "bad row range for " + r.first);
+        for (int64_t i = 0; i < t.ne[1] / 32; i++) types[(size_t)(r.second / 32 + i)] = (uint8_t)t.type;
+        kq = kq || t.type != Q3_T_Q8_0;
+    }
+    std::vector<uint32_t> off((size_t)nrg);
+    size_t qs_bytes = 0;
+    for (int i = 0; i < nrg; i++) { off[(size_t)i] = (uint32_t)(qs_bytes / 16); qs_bytes += q3_rowgroup_bytes(kq ? types[(size_t)i] : Q3_T_Q8_0, K); }
+    Q3_CHECK(qs_bytes / 16 < (1ull << 32), "matrix too large for 32-bit row-group offsets");
+    const size_t sc_bytes = (size_t)m.Npad * (K / 32) * 2;
+    const size_t meta_bytes = kq ? (size_t)m.Npad * (K / 256) * 16 : 0, ty_bytes = (size_t)((nrg + 15) & ~15), off_bytes = kq ? (size_t)((nrg * 4 + 15) & ~15) : 0;
+    blobs_.emplace_back(qs_bytes + sc_bytes + meta_bytes + ty_bytes + off_bytes);
     blobs_.back().zero();
-    m.qs = blobs_.back().p;
-    m.sc = reinterpret_cast<const uint16_t*>(blobs_.back().p + qs_bytes);
-    mat_meta_[m.qs] = blobs_.back().p + qs_bytes + sc_bytes;            // attached to the Q8Mat only if a K-quant row group shows up
-    mat_types_[m.qs] = blobs_.back().p + qs_bytes + sc_bytes + meta_bytes;
+    uint8_t* base = blobs_.back().p;
+    m.qs = base;
+    m.sc = reinterpret_cast<const uint16_t*>(base + qs_bytes);
+    mat_meta_[m.qs] = base + qs_bytes + sc_bytes;
+    mat_types_[m.qs] = base + qs_bytes + sc_bytes + meta_bytes;
+    mat_off_[m.qs] = reinterpret_cast<uint32_t*>(base + qs_bytes + sc_bytes + meta_bytes + ty_bytes);
+    if (kq) {
+        Q3_HIP(hipMemcpy(mat_types_[m.qs], types.data(), types.size(), hipMemcpyHostToDevice));
+        Q3_HIP(hipMemcpy(mat_off_[m.qs], off.data(), off.size() * 4, hipMemcpyHostToDevice));
+        m.meta = mat_meta_[m.qs]; m.rg_type = mat_types_[m.qs]; m.rg_off = mat_off_[m.qs]; m.qbytes = qs_bytes;
+        all_q8_ = false;
+    }
+    for (auto& r : rows) load_into(g, r.first, m, r.second, K);
     return m;
 }
 
 void Transformer::load_into(const Gguf& g, const std::string& name, Q8Mat& dst, int row_off, int K_expect) {
     const GgufTensor& t = g.need(name);
-    if (t.type != Q3_T_Q8_0 && t.type != Q3_T_Q5_K && t.type != Q3_T_Q6_K)
-        throw Error("tensor " + name + ": ggml type " + std::to_string(t.type) + " is not supported by the HIP path (Q8_0, Q5_K, Q6_K)");
     Q3_CHECK(t.ne[0] == K_expect, "unexpected K for " + name);
-    Q3_CHECK(row_off % 32 == 0 && row_off + t.ne[1] <= dst.Npad && t.ne[1] % 32 == 0, "bad row range for " + name);
     DevBuf<uint8_t> raw(t.nbytes);
     raw.upload(t.data, t.nbytes);
     uint8_t* qs = const_cast<uint8_t*>(dst.qs);
     uint16_t* sc = const_cast<uint16_t*>(dst.sc);
-    uint8_t* meta = mat_meta_.at(dst.qs);
-    uint8_t* types = mat_types_.at(dst.qs);
     if (t.type == Q3_T_Q8_0) {
         const size_t nblk = (size_t)t.ne[1] * (t.ne[0] / 32);
-        hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc);
+        // in a K-quant matrix the Q8_0 row groups start at their own offsets; the tile layout inside a row group is the same
+        uint8_t* q0 = qs;
+        int ro = row_off;
+        if (dst.rg_off) { // row groups of one tensor are contiguous: rebase on the first one
+            uint32_t o = 0;
+            Q3_HIP(hipMemcpy(&o, dst.rg_off + row_off / 32, 4, hipMemcpyDeviceToHost));
+            q0 = qs + (size_t)o * 16; ro = 0;
+        }
+        hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], ro, q0, sc, row_off - ro);
     } else {
         const size_t nsb = (size_t)t.ne[1] * (t.ne[0] / 256);
-        if (t.type == Q3_T_Q5_K) hipLaunchKernelGGL(k_repack_q5k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc, meta);
-        else hipLaunchKernelGGL(k_repack_q6k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, sc, meta);
-        dst.meta = meta; dst.rg_type = types; all_q8_ = false;
+        uint8_t* meta = mat_meta_.at(dst.qs);
+        if (t.type == Q3_T_Q5_K) hipLaunchKernelGGL(k_repack_q5k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, dst.rg_off, sc, meta);
+        else hipLaunchKernelGGL(k_repack_q6k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, (int)t.ne[1], (int)t.ne[0], row_off, qs, dst.rg_off, sc, meta);
     }
-    std::vector<uint8_t> ty((size_t)t.ne[1] / 32, (uint8_t)t.type);
-    Q3_HIP(hipMemcpy(types + row_off / 32, ty.data(), ty.size(), hipMemcpyHostToDevice));
     Q3_HIP(hipDeviceSynchronize());
 }
 
@@ -216,17 +257,10 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
             weight_bytes_ += lb;
             continue;
         }
-        L.wqkv = make_mat(dq + 2 * dkv, d);
-        load_into(g, p + "attn_q.weight", L.wqkv, 0, d);
-        load_into(g, p + "attn_k.weight", L.wqkv, dq, d);
-        load_into(g, p + "attn_v.weight", L.wqkv, dq + dkv, d);
-        L.wo = make_mat(d, dq);
-        load_into(g, p + "attn_output.weight", L.wo, 0, dq);
-        L.wgu = make_mat(2 * ff, d);
-        load_into(g, p + "ffn_gate.weight", L.wgu, 0, d);
-        load_into(g, p + "ffn_up.weight", L.wgu, ff, d);
-        L.wdown = make_mat(d, ff);
-        load_into(g, p + "ffn_down.weight", L.wdown, 0, ff);
+        L.wqkv = make_mat(g, {{p + "attn_q.weight", 0}, {p + "attn_k.weight", dq}, {p + "attn_v.weight", dq + dkv}}, dq + 2 * dkv, d);
+        L.wo = make_mat(g, {{p + "attn_output.weight", 0}}, d, dq);
+        L.wgu = make_mat(g, {{p + "ffn_gate.weight", 0}, {p + "ffn_up.weight", ff}}, 2 * ff, d);
+        L.wdown = make_mat(g, {{p + "ffn_down.weight", 0}}, d, ff);
         L.attn_norm = load_f32(g, p + "attn_norm.weight", d);
         L.q_norm = load_f32(g, p + "attn_q_norm.weight", 128);
         L.k_norm = load_f32(g, p + "attn_k_norm.weight", 128);
@@ -238,8 +272,7 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
     const GgufTensor& ot = g.need("output.weight");
     hp_.n_vocab = (int)ot.ne[1];
     if (float_mode_) { foutput_ = make_fmat(g, {"output.weight"}, d); fused = false; }
-    else { output_ = make_mat(hp_.n_vocab, d); load_into(g, "output.weight", output_, 0, d); }
-    if (!all_q8_) fused = false; // the fused decode kernels are Q8_0-only; K-quant files run the 9-launch sequence (same arithmetic)
+    else output_ = make_mat(g, {{"output.weight", 0}}, hp_.n_vocab, d);
     // RoPE tables: same double-precision expressions as the oracle (spec S5)
     std::vector<float> c((size_t)n_ctx * 64), s((size_t)n_ctx * 64);
     for (int p = 0; p < n_ctx; p++)

@@ -69,7 +69,7 @@ private:
     DevBuf<float> scratch_, hid_, big_logits_;
     void gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
               int out_stride, int ntok);
-    Q8Mat make_mat(int N, int K);
+    Q8Mat make_mat(const Gguf& g, const std::vector<std::pair<std::string, int>>& rows /* tensor, first row */, int N, int K);
     void load_into(const Gguf& g, const std::string& name, Q8Mat& dst, int row_off, int K_expect);
     float* load_f32(const Gguf& g, const std::string& name, int64_t n_expect);
     TfHparams hp_;
@@ -79,7 +79,7 @@ private:
     float* output_norm_ = nullptr;
     struct WeightStore { // device memory shared by every context of one model
         std::vector<DevBuf<uint8_t>> blobs; DevBuf<float> rope_cos, rope_sin; DevBuf<int32_t> d_mrope;
-        std::map<const uint8_t*, uint8_t*> mat_meta, mat_types;
+        std::map<const uint8_t*, uint8_t*> mat_meta, mat_types; std::map<const uint8_t*, uint32_t*> mat_off;
     };
     std::shared_ptr<WeightStore> ws_;
     std::vector<DevBuf<uint8_t>>& blobs_ = ws_init()->blobs;
@@ -91,7 +91,7 @@ private:
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
     bool same_seq_ = false; bool short_ctx_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
-    std::map<const uint8_t*, uint8_t*>& mat_meta_ = ws_->mat_meta; std::map<const uint8_t*, uint8_t*>& mat_types_ = ws_->mat_types;
+    std::map<const uint8_t*, uint8_t*>& mat_meta_ = ws_->mat_meta; std::map<const uint8_t*, uint8_t*>& mat_types_ = ws_->mat_types; std::map<const uint8_t*, uint32_t*>& mat_off_ = ws_->mat_off;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
     int nparts_d_ = 1;

@@ -21,7 +21,7 @@ tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
 # algorithmic bytes per launch of the weight-streaming launches of Q3TTS-1.7B-synth Q8_0 (rows x K x 1.0625 B), keyed by (kernel prefix, grid threads)
 ALG = {("k_gemm_q8_mfma<true", "196608"): 12288 * 2048 * 1.0625, ("k_gemm_q8_mfma2<true", "196608"): 12288 * 2048 * 1.0625,
        ("k_gemm_q8_mfma2<true", "98304"): 12288 * 2048 * 1.0625,
-       ("k_gateup_swiglu<1, 8>", "98304"): 12288 * 2048 * 1.0625, ("k_gateup_swiglu<1, 4>", "24576"): 6144 * 1024 * 1.0625}
+       ("k_gateup_swiglu<1, 8", "98304"): 12288 * 2048 * 1.0625, ("k_gateup_swiglu<1, 4", "24576"): 6144 * 1024 * 1.0625}
 rows, table = [], {}
 for key, v in sorted(fetch.items(), key=lambda kv: -sum(kv[1]))[:24]:
     rd = sum(v) / len(v) * 1024 * 2
