@@ -26,6 +26,11 @@ struct Q8Mat {
     const uint32_t* rg_off = nullptr;   // [Npad/32] offset of the row group's quants from qs in 16-B units (K-quant matrices only)
     const uint8_t* meta = nullptr;      // [N/32][K/256][32 rows][16 B]
     size_t qbytes = 0;                  // bytes of the quant planes as stored (0 => Npad*K)
+    // The same map by tensor, in the kernel arguments (a fused matrix is at most 3 tensors: q, k, v): row groups [part_rg0[i], part_rg0[i+1])
+    // have type part_type[i] and start at qs + 16 * part_off[i].  Kernels take type and address from here -- scalar loads of the argument
+    // block -- because reading rg_type / rg_off first would put a dependent global load (~1.5 us) in front of the whole weight stream.
+    // (plain fields, not arrays: selecting from an argument array makes the compiler copy the arguments to scratch and index them there)
+    int nparts = 0; int p1_rg0 = 0x7fffffff, p2_rg0 = 0x7fffffff; int p0_type = 0, p1_type = 0, p2_type = 0; uint32_t p0_off = 0, p1_off = 0, p2_off = 0;
     size_t bytes() const { return (qbytes ? qbytes : (size_t)Npad * K) + (size_t)Npad * (K / 32) * 2 + (meta ? (size_t)Npad * (K / 256) * 16 : 0); }
 };
 // bytes of one 32-row group of K columns in HBM, by ggml type (8 = Q8_0, 13 = Q5_K, 14 = Q6_K)

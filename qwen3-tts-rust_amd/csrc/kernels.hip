@@ -152,7 +152,7 @@ static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
 //   Q5_K: acc = fma(d*f(sc*isum1) - dmin*f(m*isum2), dx, acc)      isum2 = sum of the activation block
 //   Q6_K: acc = fma(d*f(sc0*isum_lo + sc1*isum_hi), dx, acc)        (the two 16-element halves are the sub-blocks)
 // =====================================================================================================
-template <int LPR, int MT>
+template <int LPR, int MT, int TS>
 __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                  const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride, int ntok) {
     constexpr int R = 64 / LPR;
@@ -169,16 +169,18 @@ __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, c
     if (active) {
         int row = row0 + blockIdx.x * R + r;
         if (row > w.Npad - 1) row = w.Npad - 1;
-        WSlice<LPR, true> ws;
-        ws.load(w, row >> 5, row & 31, seg, half, bil);
-        ws.finish(half);
+        wslice_dispatch<TS>(w, row >> 5, [&](auto tag) {
+            WSlice<LPR, decltype(tag)::value> ws;
+            ws.load(w, row >> 5, row & 31, seg, half, bil);
+            ws.finish(half);
 #pragma unroll
-        for (int m = 0; m < MT; m++) {
-            int tok = tok0 + m;
-            if (tok > ntok - 1) tok = ntok - 1;
-            const uint4 dxv = *reinterpret_cast<const uint4*>(xd + (size_t)tok * nb + seg * 8);
-            acc[m] = ws.chain(acc[m], xq + (size_t)tok * w.K + seg * 256, dxv, r, half, bil);
-        }
+            for (int m = 0; m < MT; m++) {
+                int tok = tok0 + m;
+                if (tok > ntok - 1) tok = ntok - 1;
+                const uint4 dxv = *reinterpret_cast<const uint4*>(xd + (size_t)tok * nb + seg * 8);
+                acc[m] = ws.chain(acc[m], xq + (size_t)tok * w.K + seg * 256, dxv, r, half, bil);
+            }
+        });
         if (q == 0) {
 #pragma unroll
             for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
@@ -202,10 +204,10 @@ static void gemv_kq_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, cons
     const int nseg = w.K >> 8, nsseg = (nseg + 7) / 8, nw = nseg < 8 ? nseg : 8;
     const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : ntok <= 4 ? 4 : 8;
     dim3 grid((nrows + R - 1) / R, nsseg, (ntok + mt - 1) / mt);
-    if (mt == 1) hipLaunchKernelGGL((k_gemv_kq<LPR, 1>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
-    else if (mt == 2) hipLaunchKernelGGL((k_gemv_kq<LPR, 2>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
-    else if (mt == 4) hipLaunchKernelGGL((k_gemv_kq<LPR, 4>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
-    else hipLaunchKernelGGL((k_gemv_kq<LPR, 8>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok);
+    if (mt == 1) Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemv_kq<LPR, 1, TS>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok));
+    else if (mt == 2) Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemv_kq<LPR, 2, TS>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok));
+    else if (mt == 4) Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemv_kq<LPR, 4, TS>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok));
+    else Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemv_kq<LPR, 8, TS>), grid, dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok));
 }
 
 template <int LPR, int MT>
@@ -231,6 +233,11 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
         int lpr = lpr_hint;
         if (!lpr) lpr = ((long)(nrows / 32) * nsseg >= 512) ? 2 : ((long)(nrows / 16) * nsseg >= 256) ? 4 : 8;
+        // Q6_K rows with 8 lanes per row: measured 14.6-62 us per launch for the predictor's 1024 x 3072 down-projection (2.1 MB; the Q5_K
+        // layers of the same shape take 4.7 us) with the same instruction and fetch counts but 4 x the SQ busy cycles
+        // (gpurun_out/pmc_kq.txt, round 2); 4 lanes per row does not show it, so Q6_K matrices stop at 4.  Q3_KQ_Q6_LPR8=1 restores 8 for A/B.
+        static const bool q6_lpr8 = [] { const char* e = std::getenv("Q3_KQ_Q6_LPR8"); return e && e[0] == '1'; }();
+        if (lpr == 8 && !lpr_hint && !q6_lpr8 && wslice_ts(w) != Q3_T_Q5_K && wslice_ts(w) != Q3_T_Q8_0) lpr = 4;
         if (lpr == 2) gemv_kq_mt<2>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
         else if (lpr == 4) gemv_kq_mt<4>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
         else gemv_kq_mt<8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);

@@ -151,7 +151,7 @@ void launch_rmsnorm_quant_wg(hipStream_t st, const NormPro& a, int d, int8_t* xq
 // ===================================================================================================
 // A: norm prologue + GEMV (K = d <= 2048, one super-segment).  EPI 0: store f32; EPI 1: atomic argmax.
 // ===================================================================================================
-template <int LPR, int MT, int EPI, bool KQ>
+template <int LPR, int MT, int EPI, int TS>
 __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nrows, NormPro a, float* __restrict__ out,
                                                       int out_stride, int ntok, ArgmaxEpi am) {
     constexpr int R = 64 / LPR;
@@ -167,26 +167,29 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
     const int tok0 = blockIdx.z * MT;
     int row = row0 + blockIdx.x * R + r;
     if (row > w.Npad - 1) row = w.Npad - 1;
-    // weight stream first: independent of the activations, flies while the prologue runs
-    WSlice<LPR, KQ> ws;
-    ws.load(w, row >> 5, row & 31, seg, half, bil);
-    for (int m = 0; m < MT; m++) { // (nwaves == K/256 by construction of the launch)
-        const int tok = tok0 + m;
-        norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
-    }
-    __syncthreads();
-    ws.finish(half);
-    float acc[MT];
+    // one body per weight type (wslice.h); every wave of the workgroup has the same row group, hence the same type and the same barriers
+    wslice_dispatch<TS>(w, row >> 5, [&](auto tag) {
+        // weight stream first: independent of the activations, flies while the prologue runs
+        WSlice<LPR, decltype(tag)::value> ws;
+        ws.load(w, row >> 5, row & 31, seg, half, bil);
+        for (int m = 0; m < MT; m++) { // (nwaves == K/256 by construction of the launch)
+            const int tok = tok0 + m;
+            norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
+        }
+        __syncthreads();
+        ws.finish(half);
+        float acc[MT];
 #pragma unroll
-    for (int m = 0; m < MT; m++) {
-        const int mm = (tok0 + m < ntok) ? m : 0; // clamp like the unfused kernel (result unused)
-        const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
-        acc[m] = ws.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, bil);
-    }
-    if (q == 0) {
+        for (int m = 0; m < MT; m++) {
+            const int mm = (tok0 + m < ntok) ? m : 0; // clamp like the unfused kernel (result unused)
+            const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
+            acc[m] = ws.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, bil);
+        }
+        if (q == 0) {
 #pragma unroll
-        for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
-    }
+            for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
+        }
+    });
     __syncthreads();
     for (int t = threadIdx.x; t < R * MT; t += blockDim.x) { // whole R-lane groups stay together (blockDim % 64 == 0)
         const int m = t / R, rr = t % R;
@@ -217,8 +220,7 @@ static void gemv_norm_launch(hipStream_t st, const Q8Mat& w, int row0, int nrows
     constexpr int R = 64 / LPR;
     const int nseg = w.K >> 8;
     dim3 grid((nrows + R - 1) / R, 1, (ntok + MT - 1) / MT);
-    if (w.rg_type) hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI, true>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
-    else hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI, false>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am);
+    Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemv_q8_norm<LPR, MT, EPI, TS>), grid, dim3(64 * nseg), 0, st, w, row0, nrows, a, out, out_stride, ntok, am));
 }
 template <int LPR, int EPI>
 static void gemv_norm_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, const NormPro& a, float* out, int out_stride, int ntok,
@@ -243,7 +245,7 @@ void launch_gemv_q8_norm(hipStream_t st, const Q8Mat& w, int row0, int nrows, co
 // ===================================================================================================
 // NSEG (waves = 256-element segments of K; 8 = the talker's K = 2048) is a template parameter only so that profiles list the talker's
 // and the predictor's launches as different kernels: bench.py's roofline line is about k_gateup_swiglu<1, 8>.
-template <int MT, int NSEG, bool KQ>
+template <int MT, int NSEG, int TS>
 __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, NormPro a, int8_t* __restrict__ aq,
                                                              uint16_t* __restrict__ ad, int ntok) {
     __shared__ float red[8][2][32 * MT];
@@ -257,46 +259,50 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
     const int seg = wave;
     const int tok0 = blockIdx.z * MT;
     const int rgG = blockIdx.x, rgU = (ff >> 5) + blockIdx.x;
-    WSlice<2, KQ> wsg, wsu;
-    if (!KQ) { // the two weight streams interleaved, as the Q8_0 kernel always issued them
-        const int nb = w.K >> 5;
-        const uint8_t* baseG = w.qs + ((size_t)rgG * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
-        const uint8_t* baseU = w.qs + ((size_t)rgU * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
+    // one body per weight type (gate and up rows of a file share their type: launch_gateup_swiglu checks)
+    wslice_dispatch<TS>(w, rgG, [&](auto tag) {
+        constexpr int WT = decltype(tag)::value;
+        WSlice<2, WT> wsg, wsu;
+        if (WT == 0) { // the two weight streams interleaved, as the Q8_0 kernel always issued them
+            const int nb = w.K >> 5;
+            const uint8_t* baseG = w.qs + ((size_t)rgG * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
+            const uint8_t* baseU = w.qs + ((size_t)rgU * nb + (size_t)seg * 8) * 1024 + half * 512 + r * 16;
 #pragma unroll
-        for (int i = 0; i < 8; i++) { wsg.wv[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wsu.wv[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
-        wsg.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
-        wsu.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
-    } else {
-        wsg.load(w, rgG, r, seg, half, 0);
-        wsu.load(w, rgU, r, seg, half, 0);
-    }
-    for (int m = 0; m < MT; m++) {
-        const int tok = tok0 + m;
-        norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
-    }
-    __syncthreads();
-    wsg.finish(half); wsu.finish(half);
-#pragma unroll
-    for (int m = 0; m < MT; m++) {
-        const int mm = (tok0 + m < ntok) ? m : 0;
-        const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
-        float ag = 0.0f, au = 0.0f;
-        if (!KQ) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) {
-                const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
-                int ig = dot16(wsg.wv[i], xv), iu = dot16(wsu.wv[i], xv);
-                ig += xor_lane<32>(ig); iu += xor_lane<32>(iu);
-                const float dx = h2f(half_of(dxv, i));
-                ag = q3_fmaf((float)ig, h2f(half_of(wsg.dwv, i)) * dx, ag);
-                au = q3_fmaf((float)iu, h2f(half_of(wsu.dwv, i)) * dx, au);
-            }
+            for (int i = 0; i < 8; i++) { wsg.wv[i] = *reinterpret_cast<const uint4*>(baseG + (size_t)i * 1024); wsu.wv[i] = *reinterpret_cast<const uint4*>(baseU + (size_t)i * 1024); }
+            wsg.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgG * nseg + seg) * 32 + r) * 8);
+            wsu.dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rgU * nseg + seg) * 32 + r) * 8);
         } else {
-            ag = wsg.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
-            au = wsu.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
+            wsg.load(w, rgG, r, seg, half, 0);
+            wsu.load(w, rgU, r, seg, half, 0);
         }
-        if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
-    }
+        for (int m = 0; m < MT; m++) {
+            const int tok = tok0 + m;
+            norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
+        }
+        __syncthreads();
+        wsg.finish(half); wsu.finish(half);
+#pragma unroll
+        for (int m = 0; m < MT; m++) {
+            const int mm = (tok0 + m < ntok) ? m : 0;
+            const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[mm][seg * 8]);
+            float ag = 0.0f, au = 0.0f;
+            if (WT == 0) {
+#pragma unroll
+                for (int i = 0; i < 8; i++) {
+                    const uint4 xv = *reinterpret_cast<const uint4*>(&xq_s[mm][seg * 256 + i * 32 + half * 16]);
+                    int ig = dot16(wsg.wv[i], xv), iu = dot16(wsu.wv[i], xv);
+                    ig += xor_lane<32>(ig); iu += xor_lane<32>(iu);
+                    const float dx = h2f(half_of(dxv, i));
+                    ag = q3_fmaf((float)ig, h2f(half_of(wsg.dwv, i)) * dx, ag);
+                    au = q3_fmaf((float)iu, h2f(half_of(wsu.dwv, i)) * dx, au);
+                }
+            } else {
+                ag = wsg.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
+                au = wsu.chain(0.0f, &xq_s[mm][seg * 256], dxv, r, half, 0);
+            }
+            if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
+        }
+    });
     __syncthreads();
     for (int t = threadIdx.x; t < 32 * MT; t += blockDim.x) {
         const int m = t >> 5, rr = t & 31, tok = tok0 + m;
@@ -318,8 +324,7 @@ void launch_gateup_swiglu(hipStream_t st, const Q8Mat& w, int ff, const NormPro&
     const int nseg = w.K >> 8;
     const int mt = ntok == 1 ? 1 : ntok == 2 ? 2 : 4;
     dim3 grid(ff / 32, 1, (ntok + mt - 1) / mt);
-#define Q3_GU(MTV, NS) do { if (w.rg_type) hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS, true>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok); \
-                            else hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS, false>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok); } while (0)
+#define Q3_GU(MTV, NS) Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gateup_swiglu<MTV, NS, TS>), grid, dim3(64 * NS), 0, st, w, ff, a, aq, ad, ntok))
 #define Q3_GU_NS(NS) do { if (mt == 1) Q3_GU(1, NS); else if (mt == 2) Q3_GU(2, NS); else Q3_GU(4, NS); } while (0)
     switch (nseg) {
         case 1: Q3_GU_NS(1); break; case 2: Q3_GU_NS(2); break; case 3: Q3_GU_NS(3); break; case 4: Q3_GU_NS(4); break;
@@ -549,7 +554,7 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
 // cross-wave dependency.  Every workgroup repeats the (tiny) attention; only workgroup 0 appends K/V to the cache.
 // Requires n = slot+1 <= 64, n_head*128 == 2048 handled as 8 segments, grp == 2.
 // ===================================================================================================
-template <int MT, bool KQ>
+template <int MT, int TS>
 __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const float* __restrict__ qkv, int qkv_stride, int n_head,
                                                     int n_kv, const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w,
                                                     float eps, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
@@ -569,150 +574,152 @@ __global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const fl
     const int seg = wave, kvh = wave;
     int row = blockIdx.x * R + r;
     if (row > w.Npad - 1) row = w.Npad - 1;
-    WSlice<LPR, KQ> ws;
-    ws.load(w, row >> 5, row & 31, seg, half, bil);
-    const float scale = 0.08838834764831845f;
-    const int jj = lane >> 4, dc = lane & 15;
-    float acc[MT];
-    for (int m = 0; m < MT; m++) {
-        acc[m] = 0.0f;
-        if (m >= ntok) continue;
-        const int tok = m;
-        const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
-        const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
-        const int page = kv.page_of(seq, 0); // n <= 64: a single page
-        const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
-        const uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
-        // ---- this token's q (2 heads), k, v for the group: norm + RoPE; lane owns the pair (l, l+64) ----
-        int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-        int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
-        if (pp < 0) pp = 0;
-        if (pp > n_ctx - 1) pp = n_ctx - 1;
-        const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
-        const float* tv = qkv + (size_t)tok * qkv_stride;
-#pragma unroll
-        for (int which = 0; which < 3; which++) { // 0,1: q heads 2w, 2w+1 ; 2: k head
-            const float* vec = tv + (which < 2 ? (size_t)(2 * kvh + which) * 128 : (size_t)(n_head + kvh) * 128);
-            const float* wn = which < 2 ? q_norm_w : k_norm_w;
-            const float x1 = vec[lane], x2 = vec[lane + 64];
-            float p = x1 * x1;
-            p = q3_fmaf(x2, x2, p);
-            const float ss = wave_sum_bfly(p);
-            const float mean = ss / 128.0f;
-            const float sc2 = 1.0f / q3_sqrtf(mean + eps);
-            const float y1 = (x1 * sc2) * wn[lane], y2 = (x2 * sc2) * wn[lane + 64];
-            float o1, o2;
-            q3_rope_pair(y1, y2, cs, sn, &o1, &o2);
-            if (which < 2) { q_s[wave][which][lane] = o1; q_s[wave][which][lane + 64] = o2; }
-            else {
-                const uint16_t k1 = f2h(o1), k2 = f2h(o2);
-                kcur_s[wave][lane] = k1; kcur_s[wave][lane + 64] = k2;
-                if (blockIdx.x == 0) {
-                    uint16_t* Kw = kv.k + (size_t)page * kv.page_stride() + head_off;
-                    Kw[((lane >> 3) * 64 + slot) * 8 + (lane & 7)] = k1;
-                    Kw[(((lane + 64) >> 3) * 64 + slot) * 8 + (lane & 7)] = k2;
-                }
-            }
-        }
-        {
-            const float* vec = tv + (size_t)(n_head + n_kv + kvh) * 128;
-            const uint16_t v1 = f2h(vec[lane]), v2 = f2h(vec[lane + 64]);
-            vcur_s[wave][lane] = v1; vcur_s[wave][lane + 64] = v2;
-            if (blockIdx.x == 0) {
-                uint16_t* Vw = kv.v + (size_t)page * kv.page_stride() + head_off;
-                Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
-            }
-        }
-        __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done before it reads them back
-        __builtin_amdgcn_wave_barrier();
-        // ---- scores for both heads: lane = position ----
-        const bool valid = lane < n, cur = lane == slot;
-        float a0 = 0.0f, a1 = 0.0f;
-#pragma unroll
-        for (int d8 = 0; d8 < 16; d8++) {
-            // cached K for position `lane` (garbage for lane >= n: masked; lane == slot: taken from LDS)
-            uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
-            if (cur) kk = *reinterpret_cast<const uint4*>(&kcur_s[wave][8 * d8]);
-            const float kf[8] = { h2f(kk.x & 0xFFFFu), h2f(kk.x >> 16), h2f(kk.y & 0xFFFFu), h2f(kk.y >> 16),
-                                  h2f(kk.z & 0xFFFFu), h2f(kk.z >> 16), h2f(kk.w & 0xFFFFu), h2f(kk.w >> 16) };
-#pragma unroll
-            for (int e = 0; e < 8; e++) { a0 = q3_fmaf(q_s[wave][0][8 * d8 + e], kf[e], a0); a1 = q3_fmaf(q_s[wave][1][8 * d8 + e], kf[e], a1); }
-        }
-        const float s0 = valid ? a0 * scale : -INFINITY, s1 = valid ? a1 * scale : -INFINITY;
-        const float m0 = wave_max_bfly(s0), m1 = wave_max_bfly(s1);
-        const float p0 = valid ? q3_expf(s0 - m0) : 0.0f, p1 = valid ? q3_expf(s1 - m1) : 0.0f;
-        p_s[wave][0][lane] = p0; p_s[wave][1][lane] = p1;
-        const float l0 = wave_sum_bfly(p0), l1 = wave_sum_bfly(p1); // spec: a_l = p_l (+ 0 + 0 + 0), then butterfly
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // ---- PV: the four sub-wave roles of k_attention_fused executed in turn; lane = (jj, dc) ----
-        float y[2][8];
-#pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-            float s01[8], s23[8];
-#pragma unroll
-            for (int ww = 0; ww < 4; ww++) {
-                float S[8];
-#pragma unroll
-                for (int i = 0; i < 8; i++) S[i] = 0.0f;
-#pragma unroll
-                for (int u = 0; u < 4; u++) {
-                    if (16 * u < n) {
-                        const int jl = 16 * u + 4 * ww + jj;
-                        const float pj = p_s[wave][hh][jl];
-                        uint4 vv = make_uint4(0, 0, 0, 0);
-                        if (jl < n) vv = (jl == slot) ? *reinterpret_cast<const uint4*>(&vcur_s[wave][dc * 8])
-                                                      : *reinterpret_cast<const uint4*>(Vb + jl * 128 + dc * 8);
-                        S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
-                        S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
-                        S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
-                        S[6] = q3_fmaf(pj, h2f(vv.w & 0xFFFFu), S[6]); S[7] = q3_fmaf(pj, h2f(vv.w >> 16), S[7]);
+    wslice_dispatch<TS>(w, row >> 5, [&](auto tag) { // one body per weight type (wslice.h)
+        WSlice<LPR, decltype(tag)::value> ws;
+        ws.load(w, row >> 5, row & 31, seg, half, bil);
+        const float scale = 0.08838834764831845f;
+        const int jj = lane >> 4, dc = lane & 15;
+        float acc[MT];
+        for (int m = 0; m < MT; m++) {
+            acc[m] = 0.0f;
+            if (m >= ntok) continue;
+            const int tok = m;
+            const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
+            const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
+            const int page = kv.page_of(seq, 0); // n <= 64: a single page
+            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
+            const uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
+            // ---- this token's q (2 heads), k, v for the group: norm + RoPE; lane owns the pair (l, l+64) ----
+            int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
+            int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
+            if (pp < 0) pp = 0;
+            if (pp > n_ctx - 1) pp = n_ctx - 1;
+            const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
+            const float* tv = qkv + (size_t)tok * qkv_stride;
+    #pragma unroll
+            for (int which = 0; which < 3; which++) { // 0,1: q heads 2w, 2w+1 ; 2: k head
+                const float* vec = tv + (which < 2 ? (size_t)(2 * kvh + which) * 128 : (size_t)(n_head + kvh) * 128);
+                const float* wn = which < 2 ? q_norm_w : k_norm_w;
+                const float x1 = vec[lane], x2 = vec[lane + 64];
+                float p = x1 * x1;
+                p = q3_fmaf(x2, x2, p);
+                const float ss = wave_sum_bfly(p);
+                const float mean = ss / 128.0f;
+                const float sc2 = 1.0f / q3_sqrtf(mean + eps);
+                const float y1 = (x1 * sc2) * wn[lane], y2 = (x2 * sc2) * wn[lane + 64];
+                float o1, o2;
+                q3_rope_pair(y1, y2, cs, sn, &o1, &o2);
+                if (which < 2) { q_s[wave][which][lane] = o1; q_s[wave][which][lane + 64] = o2; }
+                else {
+                    const uint16_t k1 = f2h(o1), k2 = f2h(o2);
+                    kcur_s[wave][lane] = k1; kcur_s[wave][lane + 64] = k2;
+                    if (blockIdx.x == 0) {
+                        uint16_t* Kw = kv.k + (size_t)page * kv.page_stride() + head_off;
+                        Kw[((lane >> 3) * 64 + slot) * 8 + (lane & 7)] = k1;
+                        Kw[(((lane + 64) >> 3) * 64 + slot) * 8 + (lane & 7)] = k2;
                     }
                 }
-#pragma unroll
-                for (int i = 0; i < 8; i++) {
-                    const float a2 = S[i] + xor_lane<16>(S[i]);
-                    const float T = a2 + xor_lane<32>(a2);
-                    if (ww == 0) s01[i] = T; else if (ww == 1) s01[i] = s01[i] + T; else if (ww == 2) s23[i] = T; else s23[i] = s23[i] + T;
+            }
+            {
+                const float* vec = tv + (size_t)(n_head + n_kv + kvh) * 128;
+                const uint16_t v1 = f2h(vec[lane]), v2 = f2h(vec[lane + 64]);
+                vcur_s[wave][lane] = v1; vcur_s[wave][lane + 64] = v2;
+                if (blockIdx.x == 0) {
+                    uint16_t* Vw = kv.v + (size_t)page * kv.page_stride() + head_off;
+                    Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
                 }
             }
-            const float L = hh == 0 ? l0 : l1;
-#pragma unroll
-            for (int i = 0; i < 8; i++) y[hh][i] = (s01[i] + s23[i]) / L;
-        }
-        // ---- int8 quantisation of the 256 outputs of this kv group (8 blocks of 32 = 4 lanes x 8) ----
-#pragma unroll
-        for (int hh = 0; hh < 2; hh++) {
-            float amax = 0.0f;
-#pragma unroll
-            for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
-            amax = fmaxf(amax, xor_lane<1>(amax));
-            amax = fmaxf(amax, xor_lane<2>(amax));
-            const float dd = amax / 127.0f;
-            const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
-            if (jj == 0) {
-                uint32_t lo = 0, hi = 0;
-#pragma unroll
-                for (int i = 0; i < 4; i++) {
-                    lo |= (uint32_t)((int)q3_rintf(y[hh][i] * id) & 0xFF) << (8 * i);
-                    hi |= (uint32_t)((int)q3_rintf(y[hh][i + 4] * id) & 0xFF) << (8 * i);
-                }
-                *reinterpret_cast<uint2*>(&xq_s[wave][hh * 128 + dc * 8]) = make_uint2(lo, hi);
-                if ((dc & 3) == 0) xd_s[wave][hh * 4 + (dc >> 2)] = f2h(dd);
+            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done before it reads them back
+            __builtin_amdgcn_wave_barrier();
+            // ---- scores for both heads: lane = position ----
+            const bool valid = lane < n, cur = lane == slot;
+            float a0 = 0.0f, a1 = 0.0f;
+    #pragma unroll
+            for (int d8 = 0; d8 < 16; d8++) {
+                // cached K for position `lane` (garbage for lane >= n: masked; lane == slot: taken from LDS)
+                uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
+                if (cur) kk = *reinterpret_cast<const uint4*>(&kcur_s[wave][8 * d8]);
+                const float kf[8] = { h2f(kk.x & 0xFFFFu), h2f(kk.x >> 16), h2f(kk.y & 0xFFFFu), h2f(kk.y >> 16),
+                                      h2f(kk.z & 0xFFFFu), h2f(kk.z >> 16), h2f(kk.w & 0xFFFFu), h2f(kk.w >> 16) };
+    #pragma unroll
+                for (int e = 0; e < 8; e++) { a0 = q3_fmaf(q_s[wave][0][8 * d8 + e], kf[e], a0); a1 = q3_fmaf(q_s[wave][1][8 * d8 + e], kf[e], a1); }
             }
+            const float s0 = valid ? a0 * scale : -INFINITY, s1 = valid ? a1 * scale : -INFINITY;
+            const float m0 = wave_max_bfly(s0), m1 = wave_max_bfly(s1);
+            const float p0 = valid ? q3_expf(s0 - m0) : 0.0f, p1 = valid ? q3_expf(s1 - m1) : 0.0f;
+            p_s[wave][0][lane] = p0; p_s[wave][1][lane] = p1;
+            const float l0 = wave_sum_bfly(p0), l1 = wave_sum_bfly(p1); // spec: a_l = p_l (+ 0 + 0 + 0), then butterfly
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // ---- PV: the four sub-wave roles of k_attention_fused executed in turn; lane = (jj, dc) ----
+            float y[2][8];
+    #pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                float s01[8], s23[8];
+    #pragma unroll
+                for (int ww = 0; ww < 4; ww++) {
+                    float S[8];
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) S[i] = 0.0f;
+    #pragma unroll
+                    for (int u = 0; u < 4; u++) {
+                        if (16 * u < n) {
+                            const int jl = 16 * u + 4 * ww + jj;
+                            const float pj = p_s[wave][hh][jl];
+                            uint4 vv = make_uint4(0, 0, 0, 0);
+                            if (jl < n) vv = (jl == slot) ? *reinterpret_cast<const uint4*>(&vcur_s[wave][dc * 8])
+                                                          : *reinterpret_cast<const uint4*>(Vb + jl * 128 + dc * 8);
+                            S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
+                            S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
+                            S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
+                            S[6] = q3_fmaf(pj, h2f(vv.w & 0xFFFFu), S[6]); S[7] = q3_fmaf(pj, h2f(vv.w >> 16), S[7]);
+                        }
+                    }
+    #pragma unroll
+                    for (int i = 0; i < 8; i++) {
+                        const float a2 = S[i] + xor_lane<16>(S[i]);
+                        const float T = a2 + xor_lane<32>(a2);
+                        if (ww == 0) s01[i] = T; else if (ww == 1) s01[i] = s01[i] + T; else if (ww == 2) s23[i] = T; else s23[i] = s23[i] + T;
+                    }
+                }
+                const float L = hh == 0 ? l0 : l1;
+    #pragma unroll
+                for (int i = 0; i < 8; i++) y[hh][i] = (s01[i] + s23[i]) / L;
+            }
+            // ---- int8 quantisation of the 256 outputs of this kv group (8 blocks of 32 = 4 lanes x 8) ----
+    #pragma unroll
+            for (int hh = 0; hh < 2; hh++) {
+                float amax = 0.0f;
+    #pragma unroll
+                for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
+                amax = fmaxf(amax, xor_lane<1>(amax));
+                amax = fmaxf(amax, xor_lane<2>(amax));
+                const float dd = amax / 127.0f;
+                const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+                if (jj == 0) {
+                    uint32_t lo = 0, hi = 0;
+    #pragma unroll
+                    for (int i = 0; i < 4; i++) {
+                        lo |= (uint32_t)((int)q3_rintf(y[hh][i] * id) & 0xFF) << (8 * i);
+                        hi |= (uint32_t)((int)q3_rintf(y[hh][i + 4] * id) & 0xFF) << (8 * i);
+                    }
+                    *reinterpret_cast<uint2*>(&xq_s[wave][hh * 128 + dc * 8]) = make_uint2(lo, hi);
+                    if ((dc & 3) == 0) xd_s[wave][hh * 4 + (dc >> 2)] = f2h(dd);
+                }
+            }
+            __builtin_amdgcn_s_waitcnt(0xc07f);
+            __builtin_amdgcn_wave_barrier();
+            // ---- this wave's o-proj segment (spec S3 block chain) ----
+            const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[wave][0]);
+            if (m == 0) ws.finish(half); // first use: the weight words have been in flight since the top of the kernel
+            acc[m] = ws.chain(acc[m], &xq_s[wave][0], dxv, r, half, bil);
+            __builtin_amdgcn_wave_barrier();
         }
-        __builtin_amdgcn_s_waitcnt(0xc07f);
-        __builtin_amdgcn_wave_barrier();
-        // ---- this wave's o-proj segment (spec S3 block chain) ----
-        const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[wave][0]);
-        if (m == 0) ws.finish(half); // first use: the weight words have been in flight since the top of the kernel
-        acc[m] = ws.chain(acc[m], &xq_s[wave][0], dxv, r, half, bil);
-        __builtin_amdgcn_wave_barrier();
-    }
-    if (q == 0) {
-#pragma unroll
-        for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
-    }
+        if (q == 0) {
+    #pragma unroll
+            for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
+        }
+    });
     __syncthreads();
     for (int t = threadIdx.x; t < R * MT; t += blockDim.x) {
         const int m = t / R, rr = t % R;
@@ -726,10 +733,10 @@ void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* 
                        const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                        const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok) {
     dim3 grid((nrows + 7) / 8);
-#define Q3_OA(MTV, KQV) hipLaunchKernelGGL((k_oproj_attn<MTV, KQV>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, \
+#define Q3_OA(MTV, KQV) hipLaunchKernelGGL((k_oproj_attn<MTV, TS>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, \
                                            rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok)
 #define Q3_OA_MT(KQV) do { if (ntok == 1) Q3_OA(1, KQV); else if (ntok == 2) Q3_OA(2, KQV); else if (ntok <= 4) Q3_OA(4, KQV); else Q3_OA(8, KQV); } while (0)
-    if (wo.rg_type) Q3_OA_MT(true); else Q3_OA_MT(false);
+    Q3_TS_SWITCH(wo, Q3_OA_MT(0));
 #undef Q3_OA_MT
 #undef Q3_OA
 }

@@ -150,6 +150,17 @@ Q8Mat Transformer::make_mat(const Gguf& g, const std::vector<std::pair<std::stri
         Q3_HIP(hipMemcpy(mat_off_[m.qs], off.data(), off.size() * 4, hipMemcpyHostToDevice));
         m.meta = mat_meta_[m.qs]; m.rg_type = mat_types_[m.qs]; m.rg_off = mat_off_[m.qs]; m.qbytes = qs_bytes;
         all_q8_ = false;
+        // tensor map for the kernel arguments: runs of equal type (rows not covered by a tensor stay Q8_0-typed zero tiles)
+        int last = -1;
+        for (int i = 0; i < nrg; i++) {
+            if (last == types[(size_t)i]) continue;
+            last = types[(size_t)i];
+            Q3_CHECK(m.nparts < 3, "more than 3 runs of weight types in one fused matrix");
+            if (m.nparts == 0) { m.p0_type = last; m.p0_off = off[(size_t)i]; }
+            else if (m.nparts == 1) { m.p1_rg0 = i; m.p1_type = last; m.p1_off = off[(size_t)i]; }
+            else { m.p2_rg0 = i; m.p2_type = last; m.p2_off = off[(size_t)i]; }
+            m.nparts++;
+        }
     }
     for (auto& r : rows) load_into(g, r.first, m, r.second, K);
     return m;
@@ -261,6 +272,7 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
         L.wo = make_mat(g, {{p + "attn_output.weight", 0}}, d, dq);
         L.wgu = make_mat(g, {{p + "ffn_gate.weight", 0}, {p + "ffn_up.weight", ff}}, 2 * ff, d);
         L.wdown = make_mat(g, {{p + "ffn_down.weight", 0}}, d, ff);
+        if (L.wgu.nparts > 1) fused = false; // k_gateup_swiglu takes the type of the up rows from the gate rows; a file that mixes them runs the unfused sequence
         L.attn_norm = load_f32(g, p + "attn_norm.weight", d);
         L.q_norm = load_f32(g, p + "attn_q_norm.weight", 128);
         L.k_norm = load_f32(g, p + "attn_k_norm.weight", 128);
