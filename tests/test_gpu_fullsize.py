@@ -90,3 +90,40 @@ def test_fullsize_codec_group16_vs_oracle(gpu, oracle, full_model):
         assert ref.shape == got[i].shape
         assert np.sqrt(np.mean((ref - got[i]) ** 2)) < 1e-4, i
     oc.close(); gd.close()
+
+
+@pytest.fixture(scope="module")
+def full_model_q5(synth_tool, full_model):
+    marker = os.path.join(full_model, ".complete_q5_k_m")
+    if not os.path.exists(marker):
+        subprocess.check_call([synth_tool, "--out", full_model, "--preset", "full", "--quant", "q5_k_m", "--seed", "1234"])
+        open(marker, "w").write("ok")
+    return full_model
+
+
+def test_fullsize_q5_k_m_packed_planes_vs_oracle(gpu, oracle, full_model_q5, vivian):
+    """Q5_K_M at the real dimensions (BASELINE configs[0] quantisation): the K-quant rows stay packed in HBM (nibble + bit planes) and every
+    kernel body that unpacks them -- fused B = 1 path (k_gemv_q8_norm / k_gateup_swiglu / k_gemv_kq for Q5_K, Q6_K and the mixed q,k,v
+    matrix) at K = 2048 / 6144 (talker) and 1024 / 3072 (predictor, two super-segments), then a 12-slot batch through the z-tiled GEMV --
+    must reproduce the oracle's Q5_K / Q6_K block arithmetic bit for bit."""
+    ge = gpu.Engine(full_model_q5, "q5_k_m", max_batch=12, max_steps=16, load_codec=False)
+    b5 = ge.bytes_per_step(1, 16)
+    prompts = []
+    for i in range(12):
+        rng = np.random.default_rng(900 + i)
+        prompts.append(ge.assets.build_core(rng.integers(0, 4000, 3 + (i % 2)).astype(np.int32), lang_id=2055, spk_emb=vivian))
+    single = ge.generate_batch([prompts[0]], max_steps=4, mask_eos=True)[0]["codes"]
+    oe = oracle.Engine(os.path.join(full_model_q5, "gguf_q5_k_m"), None, 8)
+    oc, _ = oe.generate(prompts[0], max_steps=4, mask_eos=True)
+    assert np.array_equal(oc, single)
+    res = ge.generate_batch(prompts, max_steps=3, mask_eos=True)
+    assert np.array_equal(res[0]["codes"], single[:3])
+    oc5, _ = oe.generate(prompts[5], max_steps=3, mask_eos=True)
+    oe.close()
+    assert np.array_equal(oc5, res[5]["codes"])
+    ge.close()
+    # packed planes: 0.75 / 0.875 B per weight with scales and metadata against Q8_0's 1.0625 (int8 planes were 1.19)
+    g8 = gpu.Engine(full_model_q5, "q8_0", max_batch=1, max_steps=16, load_codec=False)
+    b8 = g8.bytes_per_step(1, 16)
+    g8.close()
+    assert b5 < 0.85 * b8, (b5, b8)

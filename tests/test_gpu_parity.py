@@ -509,8 +509,8 @@ def test_engine_wide_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
 
 
 def test_q5_k_m_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
-    """BASELINE.json configs[0] quantisation (Q5_K_M = Q5_K + Q6_K rows) on the GPU: K-quant rows are expanded to int8 planes at
-    load (exact) and run through the mixed-type GEMV; tokens must equal the oracle's Q5_K/Q6_K block arithmetic bit for bit."""
+    """BASELINE.json configs[0] quantisation (Q5_K_M = Q5_K + Q6_K rows) on the GPU: K-quant rows stay packed in HBM (nibble +
+    bit planes, kernels.h), are unpacked in registers and run through the fused decode kernels / the mixed-type GEMV; tokens must equal the oracle's Q5_K/Q6_K block arithmetic bit for bit."""
     qdir = os.path.join(tiny_model, "gguf_q5_k_m")
     for name, d, npre in (("qwen3_tts_talker.gguf", 2048, 21), ("qwen3_tts_predictor.gguf", 256, 2)):
         _tf_parity(gpu, oracle, os.path.join(qdir, name), d, npre, 4, 2048)
