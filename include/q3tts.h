@@ -259,6 +259,23 @@ int q3tts_onnx_initializer(q3tts_onnx* m, int32_t i, const char** name, int32_t*
 const char* q3tts_onnx_op_kernel(const char* op_type);            /* HIP kernel serving the op, NULL = none yet */
 int q3tts_onnx_decoder_contract(q3tts_onnx* m, char* buf, int64_t cap); /* 0 satisfied, 1 missing (names in buf) */
 
+/* ---- ONNX graph execution on the GPU (second half; row a17) ----
+ * What `ort::Session::run` is to the reference's encoders (/root/reference/src/models/onnx.rs:97-121 `AudioEncoder::encode`:
+ * "input_values" [1, T] f32 -> "audio_codes" [1, F, 16] i64; :140-163 `SpeakerEncoder::encode`: "mels" [1, n, 128] f32 -> "spk_emb" [1, 2048]):
+ * a general interpreter of the operator set such exports use, one HIP launch per node, float tensors resident in HBM, shape arithmetic on the
+ * host.  dtype codes are ONNX's (1 = f32, 7 = i64, 9 = bool, fetched as f32 0 / 1).  q3tts_onnx_session_unsupported lists op types of the
+ * graph without a kernel (0 = the graph is executable). */
+typedef struct q3tts_onnx_session q3tts_onnx_session;
+int q3tts_onnx_session_open(const char* path, int32_t device, q3tts_onnx_session** out);
+void q3tts_onnx_session_close(q3tts_onnx_session* s);
+int32_t q3tts_onnx_session_unsupported(q3tts_onnx_session* s, char* buf, int64_t cap); /* count; names comma-separated in buf */
+int q3tts_onnx_session_set_input(q3tts_onnx_session* s, const char* name, int32_t dtype, const void* data, const int64_t* shape, int32_t rank);
+int q3tts_onnx_session_run(q3tts_onnx_session* s);
+int q3tts_onnx_session_output_info(q3tts_onnx_session* s, const char* name, int32_t* dtype, int32_t* rank, int64_t* shape8);
+int q3tts_onnx_session_output(q3tts_onnx_session* s, const char* name, void* dst, int64_t cap_bytes); /* f32 or i64 elements */
+int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s);                              /* kernel launches of all runs so far */
+int q3tts_onnx_op_executable(const char* op_type);                                       /* 1 when the executor runs the op */
+
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,
                      const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);

@@ -159,6 +159,7 @@ int q3tts_mel_frames(int32_t n) { const int plen = n + 768; return (plen > 1024 
 
 // ---------------- ONNX graph ingestion (host only, no GPU needed) ----------------
 #include "onnx_reader.h"
+#include "onnx_exec.h"
 struct q3tts_onnx { std::unique_ptr<OnnxModel> m; std::string text; };
 extern "C" {
 int q3tts_onnx_open(const char* path, q3tts_onnx** out) {
@@ -281,3 +282,59 @@ int64_t q3tts_tokenizer_decode(q3tts_tokenizer* t, const int32_t* ids, int32_t n
 }
 int32_t q3tts_tokenizer_vocab_size(q3tts_tokenizer* t) { return t ? t->t->vocab_size() : 0; }
 } // extern "C"
+
+// ---- ONNX graph execution (onnx_exec.h) ----
+struct q3tts_onnx_session { std::unique_ptr<q3::OnnxSession> s; };
+extern "C" {
+int q3tts_onnx_session_open(const char* path, int32_t device, q3tts_onnx_session** out) {
+    try {
+        if (!path || !out) throw q3::Error("q3tts_onnx_session_open: null argument");
+        auto* h = new q3tts_onnx_session();
+        try { h->s.reset(new q3::OnnxSession(path, device)); } catch (...) { delete h; throw; }
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+void q3tts_onnx_session_close(q3tts_onnx_session* s) { delete s; }
+int32_t q3tts_onnx_session_unsupported(q3tts_onnx_session* s, char* buf, int64_t cap) {
+    if (!s) return -1;
+    const auto v = s->s->unsupported_ops();
+    std::string t;
+    for (size_t i = 0; i < v.size(); i++) t += (i ? "," : "") + v[i];
+    if (buf && cap > 0) { const size_t n = std::min<size_t>((size_t)cap - 1, t.size()); memcpy(buf, t.data(), n); buf[n] = 0; }
+    return (int32_t)v.size();
+}
+int q3tts_onnx_session_set_input(q3tts_onnx_session* s, const char* name, int32_t dtype, const void* data, const int64_t* shape, int32_t rank) {
+    try {
+        if (!s || !name || (rank > 0 && !shape)) throw q3::Error("q3tts_onnx_session_set_input: null argument");
+        std::vector<int64_t> sh(shape, shape + rank);
+        int64_t n = 1; for (auto d : sh) { if (d < 0) throw q3::Error("negative dimension"); n *= d; }
+        if (n > 0 && !data) throw q3::Error("q3tts_onnx_session_set_input: null data");
+        s->s->set_input(name, dtype, data, sh);
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int q3tts_onnx_session_run(q3tts_onnx_session* s) {
+    try { if (!s) throw q3::Error("null session"); s->s->run(); return 0; } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int q3tts_onnx_session_output_info(q3tts_onnx_session* s, const char* name, int32_t* dtype, int32_t* rank, int64_t* shape8) {
+    try {
+        if (!s || !name) throw q3::Error("null argument");
+        const q3::XTensor& t = s->s->value(name);
+        if (t.shape.size() > 8) throw q3::Error("rank above 8");
+        if (dtype) *dtype = t.dtype;
+        if (rank) *rank = (int32_t)t.shape.size();
+        if (shape8) for (size_t i = 0; i < t.shape.size(); i++) shape8[i] = t.shape[i];
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int q3tts_onnx_session_output(q3tts_onnx_session* s, const char* name, void* dst, int64_t cap_bytes) {
+    try {
+        if (!s || !name || !dst || cap_bytes < 0) throw q3::Error("null argument");
+        s->s->fetch(s->s->value(name), dst, (size_t)cap_bytes);
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s) { return s ? (int64_t)s->s->launches() : 0; }
+int q3tts_onnx_op_executable(const char* op_type) { return op_type && q3::onnx_exec_supports(op_type) ? 1 : 0; }
+}

@@ -209,6 +209,20 @@ TtsEngine TtsEngine::new_(const std::string& model_dir, const std::string& quant
     p.model_dir = model_dir.c_str(); p.quant = quant.c_str(); p.max_batch = 1;
     if (q3tts_engine_create(&p, &t.e_) != Q3TTS_OK) throw std::runtime_error(std::string("Failed to load TtsEngine: ") + q3tts_last_error());
     t.tok_ = std::move(tok);
+    { // engine.rs:106-127: the voice-clone encoders are optional; a missing file leaves the Option empty
+        const int32_t dev = q3tts_engine_device(t.e_);
+        auto open_if = [&](const char* file, q3tts_onnx_session** out) {
+            const std::string path = model_dir + "/onnx/" + file;
+            if (FILE* f = fopen(path.c_str(), "rb")) {
+                fclose(f);
+                if (q3tts_onnx_session_open(path.c_str(), dev, out) != Q3TTS_OK) throw std::runtime_error(std::string("Failed to load ") + file + ": " + q3tts_last_error());
+                char buf[1024];
+                if (q3tts_onnx_session_unsupported(*out, buf, sizeof(buf)) > 0) throw std::runtime_error(std::string(file) + " uses operators this engine cannot execute: " + buf);
+            }
+        };
+        open_if("qwen3_tts_codec_encoder.onnx", &t.enc_);
+        open_if("qwen3_tts_speaker_encoder.onnx", &t.spk_);
+    }
     if (!t.tok_) { // engine.rs:103-104 / utils/tokenizer.rs:9-15: <model_dir>/tokenizer/tokenizer.json through the engine's own BPE reader (row f-3)
         const std::string tj = model_dir + "/tokenizer/tokenizer.json";
         if (FILE* f = fopen(tj.c_str(), "rb")) {
@@ -233,10 +247,19 @@ TtsEngine TtsEngine::new_(const std::string& model_dir, const std::string& quant
 }
 TtsEngine::TtsEngine(TtsEngine&& o) noexcept { *this = std::move(o); }
 TtsEngine& TtsEngine::operator=(TtsEngine&& o) noexcept {
-    if (this != &o) { if (e_) q3tts_engine_destroy(e_); e_ = o.e_; o.e_ = nullptr; tok_ = std::move(o.tok_); speakers_ = std::move(o.speakers_); max_steps_ = o.max_steps_; sampler_ = o.sampler_; }
+    if (this != &o) {
+        if (enc_) q3tts_onnx_session_close(enc_);
+        if (spk_) q3tts_onnx_session_close(spk_);
+        enc_ = o.enc_; spk_ = o.spk_; o.enc_ = o.spk_ = nullptr;
+        if (e_) q3tts_engine_destroy(e_); e_ = o.e_; o.e_ = nullptr; tok_ = std::move(o.tok_); speakers_ = std::move(o.speakers_); max_steps_ = o.max_steps_; sampler_ = o.sampler_;
+    }
     return *this;
 }
-TtsEngine::~TtsEngine() { if (e_) q3tts_engine_destroy(e_); }
+TtsEngine::~TtsEngine() {
+    if (enc_) q3tts_onnx_session_close(enc_);
+    if (spk_) q3tts_onnx_session_close(spk_);
+    if (e_) q3tts_engine_destroy(e_);
+}
 
 void TtsEngine::load_speakers(const std::string& dir) {
     DIR* d = opendir(dir.c_str());
@@ -322,8 +345,13 @@ AudioSample TtsEngine::generate_ids(const std::vector<int32_t>& text_ids, const 
         try { cache::load_cache(cache_path, v.audio_codes, v.speaker_embedding); hit = true; } catch (...) {} // `if let Ok(..)`: a bad cache falls through
     }
     if (!hit) {
-        try { (void)AudioSample::load_wav(ref_audio_path); } catch (const std::exception& e) { throw std::runtime_error(std::string("Failed to load audio: ") + e.what()); }
-        throw std::runtime_error("AudioEncoder not loaded (required for processing raw audio)"); // :288-290; encoders are SURVEY rows a17 / f-2
+        AudioSample a;
+        try { a = AudioSample::load_wav(ref_audio_path); } catch (const std::exception& e) { throw std::runtime_error(std::string("Failed to load audio: ") + e.what()); }
+        if (!enc_) throw std::runtime_error("AudioEncoder not loaded (required for processing raw audio)");     // :288-290
+        try { v.audio_codes = encode_audio(a.samples); } catch (const std::exception& e) { throw std::runtime_error(std::string("Audio encode failed: ") + e.what()); }
+        if (!spk_) throw std::runtime_error("SpeakerEncoder not loaded (required for processing raw audio)"); // :294-296
+        try { v.speaker_embedding = encode_speaker(a.samples); } catch (const std::exception& e) { throw std::runtime_error(std::string("Speaker extraction failed: ") + e.what()); }
+        try { cache::save_cache(cache_path, v.audio_codes, v.speaker_embedding); } catch (...) {} // `let _ = cache::save_cache(..)`
     }
     if (v.speaker_embedding.size() != 2048) throw std::runtime_error("cached speaker embedding must have 2048 values");
     return generate_with_voice_ids(text_ids, v, ins, &ref_text_ids, codes_out);
@@ -374,9 +402,81 @@ AudioSample TtsEngine::generate_with_voice_ids_stream(const std::vector<int32_t>
     return out;
 }
 
-VoiceFile TtsEngine::create_voice_file(const std::string&, const std::string&) {
-    // engine.rs:329-334: the reference returns Err when its ONNX encoders are absent; this build never has them.
-    throw std::runtime_error("AudioEncoder not loaded. Please ensure models/onnx/qwen3_tts_codec_encoder.onnx exists.");
+std::vector<int64_t> TtsEngine::encode_audio(const std::vector<float>& audio) const { // onnx.rs:97-121
+    if (!enc_) throw std::runtime_error("AudioEncoder not loaded. Please ensure models/onnx/qwen3_tts_codec_encoder.onnx exists.");
+    const int64_t shape[2] = {1, (int64_t)audio.size()};
+    if (q3tts_onnx_session_set_input(enc_, "input_values", 1, audio.data(), shape, 2) != Q3TTS_OK || q3tts_onnx_session_run(enc_) != Q3TTS_OK)
+        throw std::runtime_error(q3tts_last_error());
+    int32_t dtype = 0, rank = 0; int64_t sh[8];
+    if (q3tts_onnx_session_output_info(enc_, "audio_codes", &dtype, &rank, sh) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    if (dtype != 7) throw std::runtime_error("audio_codes is not an int64 tensor");
+    int64_t n = 1; for (int i = 0; i < rank; i++) n *= sh[i];
+    std::vector<int64_t> codes((size_t)n);
+    if (n && q3tts_onnx_session_output(enc_, "audio_codes", codes.data(), n * 8) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    return codes; // [1, frames, 16] flattened, as the reference keeps it
+}
+std::vector<float> TtsEngine::encode_speaker(const std::vector<float>& audio) const { // onnx.rs:140-163
+    if (!spk_) throw std::runtime_error("SpeakerEncoder not loaded. Please ensure models/onnx/qwen3_tts_speaker_encoder.onnx exists.");
+    const int32_t frames = q3tts_mel_frames((int32_t)audio.size());
+    if (frames <= 0) throw std::runtime_error("audio too short for the mel front end");
+    std::vector<float> mel((size_t)frames * 128);
+    if (q3tts_mel(audio.data(), (int32_t)audio.size(), mel.data()) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    const int64_t shape[3] = {1, frames, 128};
+    if (q3tts_onnx_session_set_input(spk_, "mels", 1, mel.data(), shape, 3) != Q3TTS_OK || q3tts_onnx_session_run(spk_) != Q3TTS_OK)
+        throw std::runtime_error(q3tts_last_error());
+    int32_t dtype = 0, rank = 0; int64_t sh[8];
+    if (q3tts_onnx_session_output_info(spk_, "spk_emb", &dtype, &rank, sh) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    int64_t n = 1; for (int i = 0; i < rank; i++) n *= sh[i];
+    std::vector<float> emb((size_t)n);
+    if (dtype == 7) throw std::runtime_error("spk_emb is not a float tensor");
+    if (n && q3tts_onnx_session_output(spk_, "spk_emb", emb.data(), n * 4) != Q3TTS_OK) throw std::runtime_error(q3tts_last_error());
+    return emb;
+}
+
+// hound-style WAV payload for create_voice_file (engine.rs:336-370): f32, i16 or i32 samples; stereo keeps channel 0
+static std::vector<float> read_wav_for_voice(const std::string& path) {
+    FILE* f = fopen(path.c_str(), "rb");
+    if (!f) throw std::runtime_error("WAV error: cannot open " + path);
+    std::vector<unsigned char> d;
+    unsigned char buf[65536];
+    size_t n;
+    while ((n = fread(buf, 1, sizeof(buf), f)) > 0) d.insert(d.end(), buf, buf + n);
+    fclose(f);
+    if (d.size() < 12 || memcmp(d.data(), "RIFF", 4) != 0 || memcmp(d.data() + 8, "WAVE", 4) != 0) throw std::runtime_error("WAV error: no RIFF tag found");
+    uint16_t fmt = 0, ch = 0, bits = 0; uint32_t sr = 0; bool have_fmt = false;
+    for (size_t p = 12; p + 8 <= d.size();) {
+        uint32_t len; memcpy(&len, d.data() + p + 4, 4);
+        const unsigned char* body = d.data() + p + 8;
+        const size_t avail = std::min<size_t>(len, d.size() - p - 8);
+        if (memcmp(d.data() + p, "fmt ", 4) == 0 && avail >= 16) {
+            memcpy(&fmt, body, 2); memcpy(&ch, body + 2, 2); memcpy(&sr, body + 4, 4); memcpy(&bits, body + 14, 2);
+            if (fmt == 0xFFFE && avail >= 26) memcpy(&fmt, body + 24, 2); // WAVE_FORMAT_EXTENSIBLE: the sub-format's first word
+            have_fmt = true;
+        } else if (memcmp(d.data() + p, "data", 4) == 0) {
+            if (!have_fmt) throw std::runtime_error("WAV error: data chunk before fmt chunk");
+            if (sr != 24000) throw std::runtime_error("Expected 24000Hz audio, found " + std::to_string(sr) + "Hz");
+            std::vector<float> all;
+            if (fmt == 3 && bits == 32) { all.resize(avail / 4); memcpy(all.data(), body, all.size() * 4); }
+            else if (fmt == 1 && bits == 16) { all.resize(avail / 2); for (size_t i = 0; i < all.size(); i++) { int16_t v; memcpy(&v, body + 2 * i, 2); all[i] = (float)v / 32768.0f; } }
+            else if (fmt == 1 && bits == 32) { all.resize(avail / 4); for (size_t i = 0; i < all.size(); i++) { int32_t v; memcpy(&v, body + 4 * i, 4); all[i] = (float)v / 2147483648.0f; } }
+            else throw std::runtime_error(std::string("Unsupported WAV format: ") + (fmt == 3 ? "Float" : "Int") + " " + std::to_string(bits) + " bits");
+            if (ch > 1) { std::vector<float> mono(all.size() / ch); for (size_t i = 0; i < mono.size(); i++) mono[i] = all[i * ch]; return mono; }
+            return all;
+        }
+        p += 8 + (size_t)len + (len & 1);
+    }
+    throw std::runtime_error("WAV error: no data chunk found");
+}
+
+VoiceFile TtsEngine::create_voice_file(const std::string& audio_path, const std::string& ref_text) { // engine.rs:324-387
+    if (!enc_) throw std::runtime_error("AudioEncoder not loaded. Please ensure models/onnx/qwen3_tts_codec_encoder.onnx exists.");
+    if (!spk_) throw std::runtime_error("SpeakerEncoder not loaded. Please ensure models/onnx/qwen3_tts_speaker_encoder.onnx exists.");
+    const std::vector<float> audio = read_wav_for_voice(audio_path);
+    VoiceFile v;
+    v.ref_text = ref_text;
+    v.audio_codes = encode_audio(audio);
+    v.speaker_embedding = encode_speaker(audio);
+    return v;
 }
 
 } // namespace q3tts

@@ -77,14 +77,20 @@ public:
     AudioSample generate_with_voice_ids_stream(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const ChunkFn& on_chunk,
                                                const std::vector<int32_t>* instruct_ids = nullptr, const std::vector<int32_t>* ref_text_ids = nullptr,
                                                std::vector<int32_t>* codes_out = nullptr);
-    // create_voice_file -- :324-387: needs the codec/speaker encoder graphs (not in this build)
+    // create_voice_file -- :324-387.  The two encoders are ONNX graphs run by the engine's own graph executor (q3tts_onnx_session_*, rows a17 /
+    // f-2): <model_dir>/onnx/qwen3_tts_codec_encoder.onnx ("input_values" [1, T] -> "audio_codes") and qwen3_tts_speaker_encoder.onnx ("mels"
+    // [1, n, 128] from q3tts_mel -> "spk_emb"), loaded when the files exist (engine.rs:106-127); without them the reference's errors are returned.
     VoiceFile create_voice_file(const std::string& audio_path, const std::string& ref_text);
+    bool has_encoders() const { return enc_ && spk_; }
+    std::vector<int64_t> encode_audio(const std::vector<float>& audio) const;       // AudioEncoder::encode, onnx.rs:97-121
+    std::vector<float> encode_speaker(const std::vector<float>& audio) const;       // SpeakerEncoder::encode, onnx.rs:140-163
 private:
     TtsEngine() = default;
     int build_prompt(const std::vector<int32_t>& text_ids, const VoiceFile& voice, const std::vector<int32_t>* ins, const std::vector<int32_t>* ref_text_ids,
                      std::vector<float>& prompt) const;
     void fill_request(q3tts_request& r, const std::vector<float>& prompt, int n) const;
     q3tts_engine* e_ = nullptr;
+    q3tts_onnx_session *enc_ = nullptr, *spk_ = nullptr;
     Tokenizer tok_;
     std::map<std::string, VoiceFile> speakers_;
     size_t max_steps_ = 512;

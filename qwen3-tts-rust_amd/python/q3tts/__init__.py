@@ -70,6 +70,8 @@ SYMBOLS = [
     "q3tts_comm_destroy", "q3tts_comm_voice_register", "q3tts_engine_device",
     "q3tts_onnx_open", "q3tts_onnx_close", "q3tts_onnx_counts", "q3tts_onnx_summary", "q3tts_onnx_node", "q3tts_onnx_node_input", "q3tts_onnx_node_output",
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
+    "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
+    "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
@@ -566,6 +568,64 @@ def mel(audio):
     out = np.zeros((n, 128), np.float32)
     _chk(lib().q3tts_mel(_p(audio), audio.size, _p(out)))
     return out
+
+
+class OnnxSession:
+    """ONNX graph executed on the GPU through the C ABI (q3tts_onnx_session_*): the role `ort::Session` has in the reference's encoders"""
+
+    def __init__(self, path, device=0):
+        L = lib()
+        L.q3tts_onnx_session_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.q3tts_onnx_session_close.argtypes = [C.c_void_p]
+        L.q3tts_onnx_session_unsupported.argtypes = [C.c_void_p, C.c_char_p, C.c_int64]
+        L.q3tts_onnx_session_set_input.argtypes = [C.c_void_p, C.c_char_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32]
+        L.q3tts_onnx_session_run.argtypes = [C.c_void_p]
+        L.q3tts_onnx_session_output_info.argtypes = [C.c_void_p, C.c_char_p, C.POINTER(C.c_int32), C.POINTER(C.c_int32), C.c_void_p]
+        L.q3tts_onnx_session_output.argtypes = [C.c_void_p, C.c_char_p, C.c_void_p, C.c_int64]
+        L.q3tts_onnx_session_launches.restype = C.c_int64
+        L.q3tts_onnx_session_launches.argtypes = [C.c_void_p]
+        h = C.c_void_p()
+        _chk(L.q3tts_onnx_session_open(path.encode(), device, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            lib().q3tts_onnx_session_close(self.h)
+        self.h = None
+
+    def unsupported(self):
+        buf = C.create_string_buffer(4096)
+        n = lib().q3tts_onnx_session_unsupported(self.h, buf, 4096)
+        return [x for x in buf.value.decode().split(",") if x] if n else []
+
+    def run(self, feeds, outputs):
+        """feeds: {name: ndarray (float32 or int64)}; returns {name: ndarray} for the requested graph outputs"""
+        keep = []
+        for name, arr in feeds.items():
+            a = np.ascontiguousarray(arr, dtype=np.int64 if np.issubdtype(np.asarray(arr).dtype, np.integer) else np.float32)
+            keep.append(a)
+            shape = (C.c_int64 * max(a.ndim, 1))(*a.shape)
+            _chk(lib().q3tts_onnx_session_set_input(self.h, name.encode(), 7 if a.dtype == np.int64 else 1, a.ctypes.data, shape, a.ndim))
+        _chk(lib().q3tts_onnx_session_run(self.h))
+        res = {}
+        for name in outputs:
+            dt, rk = C.c_int32(), C.c_int32()
+            shape = (C.c_int64 * 8)()
+            _chk(lib().q3tts_onnx_session_output_info(self.h, name.encode(), C.byref(dt), C.byref(rk), shape))
+            shp = tuple(shape[i] for i in range(rk.value))
+            out = np.empty(shp, dtype=np.int64 if dt.value == 7 else np.float32)
+            _chk(lib().q3tts_onnx_session_output(self.h, name.encode(), out.ctypes.data, out.nbytes))
+            res[name] = out.astype(bool) if dt.value == 9 else out
+        return res
+
+    def launches(self):
+        return lib().q3tts_onnx_session_launches(self.h)
+
+
+def onnx_op_executable(op_type):
+    L = lib()
+    L.q3tts_onnx_op_executable.argtypes = [C.c_char_p]
+    return bool(L.q3tts_onnx_op_executable(op_type.encode()))
 
 
 class OnnxModel:

@@ -64,6 +64,18 @@ def attr_float(name, v):
     return _s(1, name) + _key(2, 5) + struct.pack("<f", v) + _vi(20, 1)
 
 
+def attr_str(name, text):
+    return _s(1, name) + _ld(4, text.encode()) + _vi(20, 3)
+
+
+def attr_tensor(name, arr):
+    return _s(1, name) + _ld(5, tensor("", arr)) + _vi(20, 4)
+
+
+def attr_floats(name, vals):
+    return _s(1, name) + _ld(7, b"".join(struct.pack("<f", float(v)) for v in vals)) + _vi(20, 6)
+
+
 def node(op_type, inputs, outputs, name="", attrs=()):
     out = b"".join(_s(1, i) for i in inputs) + b"".join(_s(2, o) for o in outputs) + _s(3, name) + _s(4, op_type)
     return out + b"".join(_ld(5, a) for a in attrs)

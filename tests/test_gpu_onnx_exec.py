@@ -1,0 +1,490 @@
+"""SURVEY 8f row f-2 (second half) / row a17: the ONNX graph executor (q3tts_onnx_session_*) against numpy / torch, operator by operator and on
+encoder-shaped graphs with the reference's I/O contract (/root/reference/src/models/onnx.rs:97-121 `input_values` -> `audio_codes`,
+:140-163 `mels` -> `spk_emb`).  The graphs are written by tests/onnx_writer.py (no `onnx` package in the image); the real encoder files are not in
+the container, so these tests pin the operator semantics, not the exported networks."""
+import json
+import os
+import struct
+import subprocess
+import numpy as np
+import pytest
+
+import onnx_writer as W
+
+pytestmark = pytest.mark.gpu
+F32, I64 = W.F32, W.I64
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def run_graph(gpu, tmp_path, nodes, inits, feeds, outs, opset=17):
+    """outs: [(name, elem_type, shape)]"""
+    path = os.path.join(str(tmp_path), "g%d.onnx" % np.random.randint(1 << 30))
+    is_const = lambda n: W._s(4, "Constant") in n and W._s(4, "ConstantOfShape") not in n
+    nodes = [n for n in nodes if is_const(n)] + [n for n in nodes if not is_const(n)]  # the tests declare constants next to their use; graphs are topological
+    ins = [W.value_info(k, I64 if np.issubdtype(np.asarray(v).dtype, np.integer) else F32, list(np.asarray(v).shape)) for k, v in feeds.items()]
+    open(path, "wb").write(W.model(nodes, inits, ins, [W.value_info(n, t, s) for n, t, s in outs], opset=opset))
+    s = gpu.OnnxSession(path)
+    assert s.unsupported() == [], s.unsupported()
+    res = s.run(feeds, [n for n, _, _ in outs])
+    s.close()
+    return res
+
+
+def erf(x):
+    from scipy.special import erf as e
+    return e(x)
+
+
+def test_unary_ops(gpu, tmp_path):
+    rng = np.random.default_rng(1)
+    x = rng.standard_normal((3, 5, 7)).astype(np.float32) * 2
+    cases = {
+        "Relu": ([], lambda v: np.maximum(v, 0)), "Sigmoid": ([], lambda v: 1 / (1 + np.exp(-v))), "Tanh": ([], np.tanh), "Exp": ([], np.exp),
+        "Neg": ([], lambda v: -v), "Abs": ([], np.abs), "Sin": ([], np.sin), "Cos": ([], np.cos), "Erf": ([], erf), "Floor": ([], np.floor),
+        "Ceil": ([], np.ceil), "Round": ([], np.round), "Sign": ([], np.sign),
+        "Elu": ([W.attr_float("alpha", 0.7)], lambda v: np.where(v > 0, v, 0.7 * (np.exp(v) - 1))),
+        "LeakyRelu": ([W.attr_float("alpha", 0.1)], lambda v: np.where(v > 0, v, 0.1 * v)),
+        "HardSigmoid": ([W.attr_float("alpha", 0.25), W.attr_float("beta", 0.4)], lambda v: np.clip(0.25 * v + 0.4, 0, 1)),
+        "Gelu": ([], lambda v: 0.5 * v * (1 + erf(v / np.sqrt(2)))), "Softplus": ([], lambda v: np.log1p(np.exp(v))),
+        "Softsign": ([], lambda v: v / (1 + np.abs(v))), "HardSwish": ([], lambda v: v * np.clip(v / 6 + 0.5, 0, 1)),
+        "Selu": ([], lambda v: 1.0507009873554805 * np.where(v > 0, v, 1.6732632423543772 * (np.exp(v) - 1))),
+    }
+    nodes, outs = [], []
+    for i, (op, (attrs, _)) in enumerate(cases.items()):
+        nodes.append(W.node(op, ["x"], ["y%d" % i], attrs=attrs))
+        outs.append(("y%d" % i, F32, list(x.shape)))
+    nodes.append(W.node("Abs", ["x"], ["ax"]))
+    nodes.append(W.node("Log", ["ax"], ["ylog"])); outs.append(("ylog", F32, list(x.shape)))
+    nodes.append(W.node("Sqrt", ["ax"], ["ysqrt"])); outs.append(("ysqrt", F32, list(x.shape)))
+    nodes.append(W.node("Reciprocal", ["ax"], ["yrec"])); outs.append(("yrec", F32, list(x.shape)))
+    nodes.append(W.node("Gelu", ["x"], ["ygt"], attrs=[W.attr_str("approximate", "tanh")])); outs.append(("ygt", F32, list(x.shape)))
+    nodes.append(W.node("Clip", ["x", "lo", "hi"], ["yclip"])); outs.append(("yclip", F32, list(x.shape)))
+    inits = [W.tensor("lo", np.float32(-0.5).reshape(())), W.tensor("hi", np.float32(0.8).reshape(()))]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"x": x}, outs)
+    for i, (op, (_, fn)) in enumerate(cases.items()):
+        np.testing.assert_allclose(r["y%d" % i], fn(x.astype(np.float64)), rtol=2e-5, atol=2e-6, err_msg=op)
+    ax = np.abs(x.astype(np.float64))
+    np.testing.assert_allclose(r["ylog"], np.log(ax), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r["ysqrt"], np.sqrt(ax), rtol=2e-6)
+    np.testing.assert_allclose(r["yrec"], 1 / ax, rtol=2e-6)
+    xd = x.astype(np.float64)
+    np.testing.assert_allclose(r["ygt"], 0.5 * xd * (1 + np.tanh(np.sqrt(2 / np.pi) * (xd + 0.044715 * xd ** 3))), rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(r["yclip"], np.clip(x, -0.5, 0.8))
+
+
+def test_binary_broadcast_compare_where(gpu, tmp_path):
+    rng = np.random.default_rng(2)
+    a = rng.standard_normal((2, 1, 4, 5)).astype(np.float32)
+    b = rng.standard_normal((3, 1, 5)).astype(np.float32)
+    c = rng.standard_normal((5,)).astype(np.float32)
+    ops = {"Add": np.add, "Sub": np.subtract, "Mul": np.multiply, "Div": np.divide, "Min": np.minimum, "Max": np.maximum,
+           "PRelu": lambda x, y: np.where(x > 0, x, x * y)}
+    cmps = {"Equal": np.equal, "Less": np.less, "Greater": np.greater, "LessOrEqual": np.less_equal, "GreaterOrEqual": np.greater_equal}
+    nodes, outs = [], []
+    shp = list(np.broadcast_shapes(a.shape, b.shape))
+    for op in ops:
+        nodes.append(W.node(op, ["a", "b"], ["o_" + op])); outs.append(("o_" + op, F32, shp))
+    for op in cmps:
+        nodes.append(W.node(op, ["a", "b"], ["o_" + op])); outs.append(("o_" + op, 9, shp))
+    nodes += [W.node("Abs", ["a"], ["aa"]), W.node("Pow", ["aa", "c"], ["o_pow"]), W.node("And", ["o_Less", "o_Greater"], ["o_and"]),
+              W.node("Or", ["o_Less", "o_Equal"], ["o_or"]), W.node("Not", ["o_Less"], ["o_not"]), W.node("Where", ["o_Less", "a", "b"], ["o_where"]),
+              W.node("Sum", ["a", "b", "c"], ["o_sum3"]), W.node("Mean", ["a", "b", "c"], ["o_mean3"]), W.node("Mod", ["a", "b"], ["o_fmod"], attrs=[W.attr_int("fmod", 1)])]
+    outs += [("o_pow", F32, list(a.shape)), ("o_and", 9, shp), ("o_or", 9, shp), ("o_not", 9, shp), ("o_where", F32, shp), ("o_sum3", F32, shp), ("o_mean3", F32, shp),
+             ("o_fmod", F32, shp)]
+    r = run_graph(gpu, tmp_path, nodes, [], {"a": a, "b": b, "c": c}, outs)
+    for op, fn in ops.items():
+        np.testing.assert_allclose(r["o_" + op], fn(a, b), rtol=1e-6, err_msg=op)
+    for op, fn in cmps.items():
+        np.testing.assert_array_equal(r["o_" + op], fn(a, b), err_msg=op)
+    np.testing.assert_allclose(r["o_pow"], np.abs(a).astype(np.float64) ** c, rtol=3e-5)
+    np.testing.assert_array_equal(r["o_and"], np.zeros(shp, bool))
+    np.testing.assert_array_equal(r["o_or"], np.less_equal(a, b))
+    np.testing.assert_array_equal(r["o_not"], ~np.less(a, b))
+    np.testing.assert_array_equal(r["o_where"], np.where(a < b, a, b))
+    np.testing.assert_allclose(r["o_sum3"], a + b + c, rtol=1e-6)
+    np.testing.assert_allclose(r["o_mean3"], (a + b + c) / 3, rtol=1e-6)
+    np.testing.assert_allclose(r["o_fmod"], np.fmod(a, b), rtol=1e-5, atol=1e-6)
+
+
+def test_shape_arithmetic_and_data_movement(gpu, tmp_path):
+    """the Shape -> Gather -> Concat -> Reshape chains every exporter emits run on the host; the data ops they parameterise run on the device"""
+    rng = np.random.default_rng(3)
+    x = rng.standard_normal((2, 6, 4, 5)).astype(np.float32)
+    i0 = lambda name, v: W.tensor(name, np.asarray(v, np.int64))
+    inits = [i0("c0", 0), i0("c1", [1]), i0("cm1", [-1]), i0("c2", [2]), i0("ax01", [0, 1]), i0("st", [1, 4]), i0("en", [5, -9223372036854775807 - 1 + 1]),
+             i0("sax", [1, 3]), i0("sst", [2, -1]), i0("idx", [[3, 0], [5, 5]]), i0("rep", [1, 2, 1, 3]), i0("splits", [1, 2, 3]), i0("c3", 3), i0("c20", 20)]
+    nodes = [
+        W.node("Shape", ["x"], ["shp"]),                                  # [2,6,4,5]
+        W.node("Gather", ["shp", "c0"], ["n"]),                           # 2 (scalar)
+        W.node("Unsqueeze", ["n", "c0u"], ["n1"]),
+        W.node("Constant", [], ["c0u"], attrs=[W.attr_tensor("value", np.asarray([0], np.int64))]),
+        W.node("Slice", ["shp", "c2", "c4"], ["tail"]),                   # [4,5]
+        W.node("Constant", [], ["c4"], attrs=[W.attr_ints("value_ints", [4])]),
+        W.node("ReduceProd", ["tail"], ["tp"], attrs=[W.attr_int("keepdims", 1)]),  # [20]
+        W.node("Concat", ["n1", "cm1", "tp"], ["newshape"], attrs=[W.attr_int("axis", 0)]),
+        W.node("Reshape", ["x", "newshape"], ["y_reshape"]),              # [2,6,20]
+        W.node("Transpose", ["x"], ["y_tr"], attrs=[W.attr_ints("perm", [0, 2, 3, 1])]),
+        W.node("Slice", ["x", "st", "en", "sax", "sst"], ["y_slice"]),    # axis1 1:5:2, axis3 4:begin:-1
+        W.node("Gather", ["x", "idx"], ["y_gather"], attrs=[W.attr_int("axis", 1)]),
+        W.node("Tile", ["x", "rep"], ["y_tile"]),
+        W.node("Split", ["x", "splits"], ["s0", "s1", "s2"], attrs=[W.attr_int("axis", 1)]),
+        W.node("Concat", ["s2", "s0", "s1"], ["y_cat"], attrs=[W.attr_int("axis", 1)]),
+        W.node("Flatten", ["x"], ["y_flat"], attrs=[W.attr_int("axis", 2)]),
+        W.node("Range", ["c0", "c20", "c3"], ["rng"]),                    # 0,3,...,18 (7 values, host)
+        W.node("Cast", ["rng"], ["rngf"], attrs=[W.attr_int("to", 1)]),
+        W.node("ConstantOfShape", ["c2b"], ["ones"], attrs=[W.attr_tensor("value", np.asarray([1.5], np.float32))]),
+        W.node("Constant", [], ["c2b"], attrs=[W.attr_tensor("value", np.asarray([2, 1], np.int64))]),
+        W.node("Mul", ["ones", "rngf"], ["y_outer"]),                     # [2,1] x [7] -> [2,7]
+        W.node("Expand", ["rngf", "eshape"], ["y_expand"]),
+        W.node("Constant", [], ["eshape"], attrs=[W.attr_tensor("value", np.asarray([3, 1, 7], np.int64))]),
+        W.node("Squeeze", ["y_expand", "c1"], ["y_squeeze"]),
+        W.node("Size", ["x"], ["sz"]),
+        W.node("Div", ["sz", "c20"], ["y_idiv"]),                         # 240 // 20 on the host, integer semantics
+        W.node("Cast", ["x"], ["xi"], attrs=[W.attr_int("to", 7)]),
+        W.node("Cast", ["xi"], ["y_trunc"], attrs=[W.attr_int("to", 1)]),
+    ]
+    outs = [("y_reshape", F32, [2, 6, 20]), ("y_tr", F32, [2, 4, 5, 6]), ("y_slice", F32, [2, 2, 4, 5]), ("y_gather", F32, [2, 2, 2, 4, 5]), ("y_tile", F32, [2, 12, 4, 15]),
+            ("y_cat", F32, [2, 6, 4, 5]), ("y_flat", F32, [12, 20]), ("y_outer", F32, [2, 7]), ("y_expand", F32, [3, 1, 7]), ("y_squeeze", F32, [3, 7]), ("y_idiv", I64, []),
+            ("y_trunc", F32, list(x.shape)), ("shp", I64, [4])]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"x": x}, outs)
+    np.testing.assert_array_equal(r["shp"], [2, 6, 4, 5])
+    np.testing.assert_array_equal(r["y_reshape"], x.reshape(2, 6, 20))
+    np.testing.assert_array_equal(r["y_tr"], x.transpose(0, 2, 3, 1))
+    np.testing.assert_array_equal(r["y_slice"], x[:, 1:5:2, :, 4::-1])
+    np.testing.assert_array_equal(r["y_gather"], np.take(x, [[3, 0], [5, 5]], axis=1))
+    np.testing.assert_array_equal(r["y_tile"], np.tile(x, (1, 2, 1, 3)))
+    np.testing.assert_array_equal(r["y_cat"], np.concatenate([x[:, 3:], x[:, :1], x[:, 1:3]], axis=1))
+    np.testing.assert_array_equal(r["y_flat"], x.reshape(12, 20))
+    rg = np.arange(0, 20, 3, dtype=np.float32)
+    np.testing.assert_array_equal(r["y_outer"], np.full((2, 1), 1.5, np.float32) * rg)
+    np.testing.assert_array_equal(r["y_expand"], np.broadcast_to(rg, (3, 1, 7)))
+    np.testing.assert_array_equal(r["y_squeeze"], np.broadcast_to(rg, (3, 7)))
+    assert int(r["y_idiv"].reshape(-1)[0]) == 12
+    np.testing.assert_array_equal(r["y_trunc"], np.trunc(x))
+
+
+def test_reductions_and_normalisations(gpu, tmp_path):
+    rng = np.random.default_rng(4)
+    x = rng.standard_normal((3, 4, 300)).astype(np.float32)
+    xd = x.astype(np.float64)
+    g = rng.standard_normal(300).astype(np.float32); b = rng.standard_normal(300).astype(np.float32)
+    cg = rng.standard_normal(4).astype(np.float32); cb = rng.standard_normal(4).astype(np.float32)
+    cm = rng.standard_normal(4).astype(np.float32); cv = (rng.random(4) + 0.5).astype(np.float32)
+    ax = lambda name, v: W.tensor(name, np.asarray(v, np.int64))
+    inits = [ax("a2", [2]), ax("a02", [0, 2]), ax("a1", [1]), ax("am1", -1), W.tensor("g", g), W.tensor("b", b), W.tensor("cg", cg), W.tensor("cb", cb),
+             W.tensor("cm", cm), W.tensor("cv", cv)]
+    red = {"ReduceMean": lambda v, a, k: v.mean(axis=a, keepdims=k), "ReduceMax": lambda v, a, k: v.max(axis=a, keepdims=k),
+           "ReduceMin": lambda v, a, k: v.min(axis=a, keepdims=k), "ReduceL2": lambda v, a, k: np.sqrt((v * v).sum(axis=a, keepdims=k)),
+           "ReduceSumSquare": lambda v, a, k: (v * v).sum(axis=a, keepdims=k), "ReduceL1": lambda v, a, k: np.abs(v).sum(axis=a, keepdims=k),
+           "ReduceLogSumExp": lambda v, a, k: np.log(np.exp(v).sum(axis=a, keepdims=k))}
+    nodes, outs = [], []
+    for op in red:                                    # opset 18 form: axes as an input
+        nodes.append(W.node(op, ["x", "a02"], ["r_" + op], attrs=[W.attr_int("keepdims", 0)])); outs.append(("r_" + op, F32, [4]))
+    nodes += [W.node("ReduceSum", ["x", "a2"], ["r_sum"]), W.node("Slice", ["x", "a0s", "a2e", "a2"], ["xs"]),
+              W.node("ReduceProd", ["xs", "a1"], ["r_prod"], attrs=[W.attr_int("keepdims", 0)]), W.node("Constant", [], ["a0s"], attrs=[W.attr_ints("value_ints", [0])]),
+              W.node("Constant", [], ["a2e"], attrs=[W.attr_ints("value_ints", [3])]),
+              W.node("ReduceMean", ["x"], ["r_all"], attrs=[W.attr_int("keepdims", 0)]),
+              W.node("ArgMax", ["x"], ["r_argmax"], attrs=[W.attr_int("axis", 2), W.attr_int("keepdims", 0)]),
+              W.node("ArgMin", ["x"], ["r_argmin"], attrs=[W.attr_int("axis", 1)]),
+              W.node("Softmax", ["x"], ["r_sm_last"]), W.node("Softmax", ["x"], ["r_sm_mid"], attrs=[W.attr_int("axis", 1)]),
+              W.node("LogSoftmax", ["x"], ["r_lsm"], attrs=[W.attr_int("axis", -1)]),
+              W.node("LayerNormalization", ["x", "g", "b"], ["r_ln"], attrs=[W.attr_float("epsilon", 1e-5)]),
+              W.node("InstanceNormalization", ["x", "cg", "cb"], ["r_in"], attrs=[W.attr_float("epsilon", 1e-5)]),
+              W.node("BatchNormalization", ["x", "cg", "cb", "cm", "cv"], ["r_bn"], attrs=[W.attr_float("epsilon", 1e-5)]),
+              W.node("CumSum", ["x", "am1"], ["r_cs"]), W.node("CumSum", ["x", "a1s"], ["r_cs_rev"], attrs=[W.attr_int("reverse", 1), W.attr_int("exclusive", 1)]),
+              W.node("Constant", [], ["a1s"], attrs=[W.attr_int("value_int", 1)]),
+              W.node("GlobalAveragePool", ["x"], ["r_gap"])]
+    outs += [("r_sum", F32, [3, 4, 1]), ("r_prod", F32, [3, 3]), ("r_all", F32, []), ("r_argmax", I64, [3, 4]), ("r_argmin", I64, [3, 1, 300]),
+             ("r_sm_last", F32, list(x.shape)), ("r_sm_mid", F32, list(x.shape)), ("r_lsm", F32, list(x.shape)), ("r_ln", F32, list(x.shape)), ("r_in", F32, list(x.shape)),
+             ("r_bn", F32, list(x.shape)), ("r_cs", F32, list(x.shape)), ("r_cs_rev", F32, list(x.shape)), ("r_gap", F32, [3, 4, 1])]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"x": x}, outs, opset=18)
+    for op, fn in red.items():
+        np.testing.assert_allclose(r["r_" + op], fn(xd, (0, 2), False), rtol=3e-5, atol=1e-5, err_msg=op)
+    np.testing.assert_allclose(r["r_sum"], xd.sum(axis=2, keepdims=True), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(r["r_prod"], xd[:, :, :3].prod(axis=1), rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(r["r_all"], xd.mean(), rtol=1e-4, atol=1e-6)
+    np.testing.assert_array_equal(r["r_argmax"], x.argmax(axis=2))
+    np.testing.assert_array_equal(r["r_argmin"], x.argmin(axis=1)[:, None, :])
+    sm = lambda v, a: np.exp(v - v.max(axis=a, keepdims=True)) / np.exp(v - v.max(axis=a, keepdims=True)).sum(axis=a, keepdims=True)
+    np.testing.assert_allclose(r["r_sm_last"], sm(xd, 2), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(r["r_sm_mid"], sm(xd, 1), rtol=2e-5, atol=1e-7)
+    np.testing.assert_allclose(r["r_lsm"], np.log(sm(xd, 2)), rtol=2e-5, atol=2e-6)
+    norm = lambda v, a: (v - v.mean(axis=a, keepdims=True)) / np.sqrt(v.var(axis=a, keepdims=True) + 1e-5)
+    np.testing.assert_allclose(r["r_ln"], norm(xd, 2) * g + b, rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(r["r_in"], norm(xd, 2) * cg[None, :, None] + cb[None, :, None], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(r["r_bn"], (xd - cm[None, :, None]) / np.sqrt(cv[None, :, None] + 1e-5) * cg[None, :, None] + cb[None, :, None], rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(r["r_cs"], np.cumsum(xd, axis=2), rtol=1e-5, atol=1e-4)
+    rev = np.flip(np.cumsum(np.flip(xd, 1), axis=1), 1) - xd
+    np.testing.assert_allclose(r["r_cs_rev"], rev, rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["r_gap"], xd.mean(axis=2, keepdims=True), rtol=1e-5, atol=1e-6)
+
+
+def test_matmul_gemm(gpu, tmp_path):
+    rng = np.random.default_rng(5)
+    a = rng.standard_normal((2, 3, 17, 33)).astype(np.float32); b = rng.standard_normal((2, 3, 33, 21)).astype(np.float32)
+    w = rng.standard_normal((33, 40)).astype(np.float32); v = rng.standard_normal(33).astype(np.float32)
+    bb = rng.standard_normal((1, 3, 33, 21)).astype(np.float32)
+    ga = rng.standard_normal((19, 33)).astype(np.float32); gb = rng.standard_normal((40, 33)).astype(np.float32); gc = rng.standard_normal(40).astype(np.float32)
+    gat = np.ascontiguousarray(ga.T); gc2 = rng.standard_normal((19, 1)).astype(np.float32)
+    inits = [W.tensor("w", w), W.tensor("v", v), W.tensor("gb", gb), W.tensor("gc", gc), W.tensor("gc2", gc2)]
+    nodes = [W.node("MatMul", ["a", "b"], ["m_batched"]), W.node("MatMul", ["a", "w"], ["m_weight"]), W.node("MatMul", ["a", "v"], ["m_vec"]),
+             W.node("MatMul", ["a", "bb"], ["m_bcast"]),
+             W.node("Gemm", ["ga", "gb", "gc"], ["g_tb"], attrs=[W.attr_int("transB", 1), W.attr_float("alpha", 0.5), W.attr_float("beta", 2.0)]),
+             W.node("Gemm", ["gat", "gb", "gc2"], ["g_tab"], attrs=[W.attr_int("transA", 1), W.attr_int("transB", 1)])]
+    outs = [("m_batched", F32, [2, 3, 17, 21]), ("m_weight", F32, [2, 3, 17, 40]), ("m_vec", F32, [2, 3, 17]), ("m_bcast", F32, [2, 3, 17, 21]),
+            ("g_tb", F32, [19, 40]), ("g_tab", F32, [19, 40])]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"a": a, "b": b, "bb": bb, "ga": ga, "gat": gat}, outs)
+    d = lambda z: z.astype(np.float64)
+    np.testing.assert_allclose(r["m_batched"], d(a) @ d(b), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["m_weight"], d(a) @ d(w), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["m_vec"], d(a) @ d(v), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["m_bcast"], d(a) @ d(bb), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["g_tb"], 0.5 * d(ga) @ d(gb).T + 2.0 * d(gc), rtol=1e-5, atol=1e-5)
+    np.testing.assert_allclose(r["g_tab"], d(ga) @ d(gb).T + d(gc2), rtol=1e-5, atol=1e-5)
+
+
+def test_convolutions_and_pad_vs_torch(gpu, tmp_path):
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(6)
+    x1 = rng.standard_normal((2, 8, 50)).astype(np.float32)
+    w1 = rng.standard_normal((12, 4, 5)).astype(np.float32); b1 = rng.standard_normal(12).astype(np.float32)      # groups 2, stride 2, dilation 2, pads (3, 1)
+    w1s = rng.standard_normal((6, 8, 7)).astype(np.float32)                                                       # SAME_UPPER, stride 3
+    wt1 = rng.standard_normal((8, 3, 4)).astype(np.float32); bt1 = rng.standard_normal(6).astype(np.float32)      # ConvTranspose: groups 2 -> 6 channels, stride 3, pads (1, 2), output_padding 1
+    x2 = rng.standard_normal((1, 4, 9, 11)).astype(np.float32)
+    w2 = rng.standard_normal((6, 4, 3, 2)).astype(np.float32); b2 = rng.standard_normal(6).astype(np.float32)     # 2-D: strides (2, 1), pads (1, 0, 1, 1)
+    wt2 = rng.standard_normal((4, 5, 2, 3)).astype(np.float32)                                                    # 2-D transposed: strides (2, 2), dilations (1, 2)
+    inits = [W.tensor(n, v) for n, v in (("w1", w1), ("b1", b1), ("w1s", w1s), ("wt1", wt1), ("bt1", bt1), ("w2", w2), ("b2", b2), ("wt2", wt2))]
+    inits += [W.tensor("pads", np.asarray([0, 0, 2, 0, 0, 3], np.int64)), W.tensor("padv", np.float32(0.25).reshape(()))]
+    nodes = [
+        W.node("Conv", ["x1", "w1", "b1"], ["c1"], attrs=[W.attr_int("group", 2), W.attr_ints("strides", [2]), W.attr_ints("dilations", [2]), W.attr_ints("pads", [3, 1])]),
+        W.node("Conv", ["x1", "w1s"], ["c1s"], attrs=[W.attr_str("auto_pad", "SAME_UPPER"), W.attr_ints("strides", [3])]),
+        W.node("ConvTranspose", ["x1", "wt1", "bt1"], ["t1"], attrs=[W.attr_int("group", 2), W.attr_ints("strides", [3]), W.attr_ints("pads", [1, 2]), W.attr_ints("output_padding", [1])]),
+        W.node("Conv", ["x2", "w2", "b2"], ["c2"], attrs=[W.attr_ints("strides", [2, 1]), W.attr_ints("pads", [1, 0, 1, 1])]),
+        W.node("ConvTranspose", ["x2", "wt2"], ["t2"], attrs=[W.attr_ints("strides", [2, 2]), W.attr_ints("dilations", [1, 2])]),
+        W.node("Pad", ["x1", "pads", "padv"], ["p_const"]),
+        W.node("Pad", ["x1", "pads"], ["p_reflect"], attrs=[W.attr_str("mode", "reflect")]),
+        W.node("Pad", ["x1", "pads"], ["p_edge"], attrs=[W.attr_str("mode", "edge")]),
+    ]
+    T = torch.from_numpy
+    ref = {
+        "c1": Fn.conv1d(Fn.pad(T(x1), (3, 1)), T(w1), T(b1), stride=2, dilation=2, groups=2),
+        "c1s": Fn.conv1d(Fn.pad(T(x1), (2, 3)), T(w1s), None, stride=3),           # in 50, stride 3 -> 17 outputs, total pad 5 = (2, 3)
+        "t1": Fn.conv_transpose1d(T(x1), T(wt1), T(bt1), stride=3, padding=0, output_padding=0, groups=2),
+        "c2": Fn.conv2d(Fn.pad(T(x2), (0, 1, 1, 1)), T(w2), T(b2), stride=(2, 1)),
+        "t2": Fn.conv_transpose2d(T(x2), T(wt2), None, stride=(2, 2), dilation=(1, 2)),
+        "p_const": Fn.pad(T(x1), (2, 3), value=0.25), "p_reflect": Fn.pad(T(x1), (2, 3), mode="reflect"), "p_edge": Fn.pad(T(x1), (2, 3), mode="replicate"),
+    }
+    # pads (1, 2) + output_padding 1: output position o is position o + 1 of the unpadded result; length (50 - 1) * 3 - 1 - 2 + 4 + 1 = 149
+    ref["t1"] = ref["t1"][:, :, 1:150]
+    outs = [(k, F32, list(v.shape)) for k, v in ref.items()]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"x1": x1, "x2": x2}, outs)
+    for k, v in ref.items():
+        assert r[k].shape == tuple(v.shape), (k, r[k].shape, v.shape)
+        np.testing.assert_allclose(r[k], v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
+
+
+def test_speaker_encoder_shaped_graph(gpu, tmp_path):
+    """`mels` [1, n, 128] -> `spk_emb` [1, 2048] (onnx.rs:140-163): a small TDNN / squeeze-excitation / attentive-statistics-pooling network with the
+    reference's input and output names, against the same network written in torch"""
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(7)
+    n, C = 37, 24
+    mels = rng.standard_normal((1, n, 128)).astype(np.float32)
+    P = {k: (rng.standard_normal(s) * sc).astype(np.float32) for k, s, sc in (
+        ("w0", (C, 128, 5), 0.05), ("b0", (C,), 0.1), ("bn_g", (C,), 1.0), ("bn_b", (C,), 0.1), ("bn_m", (C,), 0.1),
+        ("wd", (C // 2, C // 2, 3), 0.2), ("bd", (C // 2,), 0.1), ("se1", (6, C, 1), 0.2), ("se1b", (6,), 0.1), ("se2", (C, 6, 1), 0.2), ("se2b", (C,), 0.1),
+        ("att1", (8, C, 1), 0.2), ("att1b", (8,), 0.1), ("att2", (C, 8, 1), 0.2), ("att2b", (C,), 0.1), ("fc", (2048, 2 * C), 0.1), ("fcb", (2048,), 0.1))}
+    P["bn_v"] = (rng.random(C) + 0.5).astype(np.float32)
+    inits = [W.tensor(k, v) for k, v in P.items()] + [W.tensor("ax2", np.asarray([2], np.int64)), W.tensor("eps", np.float32(1e-5).reshape(())),
+                                                      W.tensor("big", np.float32(1e9).reshape(())), W.tensor("half", np.asarray([C // 2, C // 2], np.int64))]
+    nodes = [
+        W.node("Transpose", ["mels"], ["x"], attrs=[W.attr_ints("perm", [0, 2, 1])]),
+        W.node("Conv", ["x", "w0", "b0"], ["h0"], attrs=[W.attr_ints("pads", [2, 2])]),
+        W.node("Relu", ["h0"], ["h0r"]),
+        W.node("BatchNormalization", ["h0r", "bn_g", "bn_b", "bn_m", "bn_v"], ["h1"]),
+        W.node("Split", ["h1", "half"], ["ha", "hb"], attrs=[W.attr_int("axis", 1)]),                      # Res2Net-style: second half through a dilated conv
+        W.node("Conv", ["hb", "wd", "bd"], ["hbd"], attrs=[W.attr_ints("dilations", [2]), W.attr_ints("pads", [2, 2])]),
+        W.node("Concat", ["ha", "hbd"], ["h2"], attrs=[W.attr_int("axis", 1)]),
+        W.node("ReduceMean", ["h2"], ["s"], attrs=[W.attr_ints("axes", [2]), W.attr_int("keepdims", 1)]),   # squeeze-excitation
+        W.node("Conv", ["s", "se1", "se1b"], ["s1"]), W.node("Relu", ["s1"], ["s1r"]), W.node("Conv", ["s1r", "se2", "se2b"], ["s2"]), W.node("Sigmoid", ["s2"], ["gate"]),
+        W.node("Mul", ["h2", "gate"], ["h3"]), W.node("Add", ["h3", "h1"], ["h4"]),
+        W.node("Conv", ["h4", "att1", "att1b"], ["a1"]), W.node("Tanh", ["a1"], ["a1t"]), W.node("Conv", ["a1t", "att2", "att2b"], ["a2"]),
+        W.node("Softmax", ["a2"], ["wgt"], attrs=[W.attr_int("axis", 2)]),                                    # attentive statistics pooling
+        W.node("Mul", ["h4", "wgt"], ["hw"]), W.node("ReduceSum", ["hw", "ax2"], ["mu"], attrs=[W.attr_int("keepdims", 1)]),
+        W.node("Mul", ["h4", "h4"], ["hsq"]), W.node("Mul", ["hsq", "wgt"], ["hsqw"]), W.node("ReduceSum", ["hsqw", "ax2"], ["ex2"], attrs=[W.attr_int("keepdims", 1)]),
+        W.node("Mul", ["mu", "mu"], ["mu2"]), W.node("Sub", ["ex2", "mu2"], ["var"]), W.node("Clip", ["var", "eps", "big"], ["varc"]), W.node("Sqrt", ["varc"], ["sd"]),
+        W.node("Concat", ["mu", "sd"], ["stat"], attrs=[W.attr_int("axis", 1)]), W.node("Flatten", ["stat"], ["statf"]),
+        W.node("Gemm", ["statf", "fc", "fcb"], ["spk_emb"], attrs=[W.attr_int("transB", 1)]),
+    ]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"mels": mels}, [("spk_emb", F32, [1, 2048])], opset=13)
+    T = lambda k: torch.from_numpy(P[k]).double()
+    x = torch.from_numpy(mels).double().transpose(1, 2)
+    h1 = Fn.batch_norm(Fn.relu(Fn.conv1d(x, T("w0"), T("b0"), padding=2)), T("bn_m"), T("bn_v"), T("bn_g"), T("bn_b"), eps=1e-5)
+    ha, hb = h1[:, :C // 2], h1[:, C // 2:]
+    h2 = torch.cat([ha, Fn.conv1d(hb, T("wd"), T("bd"), dilation=2, padding=2)], 1)
+    gate = torch.sigmoid(Fn.conv1d(Fn.relu(Fn.conv1d(h2.mean(2, keepdim=True), T("se1"), T("se1b"))), T("se2"), T("se2b")))
+    h4 = h2 * gate + h1
+    wgt = torch.softmax(Fn.conv1d(torch.tanh(Fn.conv1d(h4, T("att1"), T("att1b"))), T("att2"), T("att2b")), dim=2)
+    mu = (h4 * wgt).sum(2, keepdim=True)
+    sd = torch.sqrt(((h4 * h4 * wgt).sum(2, keepdim=True) - mu * mu).clamp(1e-5, 1e9))
+    ref = Fn.linear(torch.cat([mu, sd], 1).flatten(1), T("fc"), T("fcb")).numpy()
+    assert r["spk_emb"].shape == (1, 2048)
+    np.testing.assert_allclose(r["spk_emb"], ref, rtol=2e-4, atol=2e-4)
+
+
+def _codec_encoder_case(seed, Tn, D, NQ, CB):
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(seed)
+    wav = (rng.standard_normal((1, Tn)) * 0.3).astype(np.float32)
+    P = {k: (rng.standard_normal(s) * sc).astype(np.float32) for k, s, sc in (
+        ("w1", (8, 1, 7), 0.3), ("b1", (8,), 0.1), ("w2", (D, 8, 8), 0.15), ("b2", (D,), 0.1), ("w3", (D, D, 16), 0.08), ("b3", (D,), 0.1),
+        ("ln_g", (D,), 1.0), ("ln_b", (D,), 0.1), ("wq", (D, D), 0.3), ("wk", (D, D), 0.3), ("wv", (D, D), 0.3), ("wo", (D, D), 0.3), ("cb", (NQ, CB, D), 1.0))}
+    Tt = lambda k: torch.from_numpy(P[k]).double()
+    x = torch.from_numpy(wav).double()[:, None]
+    h = Fn.conv1d(Fn.elu(Fn.conv1d(Fn.elu(Fn.conv1d(x, Tt("w1"), Tt("b1"), padding=3)), Tt("w2"), Tt("b2"), stride=4, padding=2)), Tt("w3"), Tt("b3"), stride=8, padding=4)
+    t = h.transpose(1, 2)
+    tn = Fn.layer_norm(t, (D,), Tt("ln_g"), Tt("ln_b"), 1e-5)
+    pr = torch.softmax((tn @ Tt("wq")) @ (tn @ Tt("wk")).transpose(1, 2) / np.sqrt(D), -1)
+    rsd = t + (pr @ (tn @ Tt("wv"))) @ Tt("wo")
+    codes, margins = [], []
+    cb = torch.from_numpy(P["cb"]).double()
+    for qn in range(NQ):
+        dist = (cb[qn] ** 2).sum(1) - 2 * rsd @ cb[qn].T
+        srt = torch.sort(dist, dim=-1).values
+        margins.append((srt[..., 1] - srt[..., 0]).min().item())
+        c = dist.argmin(-1)
+        codes.append(c)
+        rsd = rsd - cb[qn][c]
+    return wav, P, torch.stack(codes, -1).numpy(), rsd.numpy(), min(margins)
+
+
+def test_codec_encoder_shaped_graph(gpu, tmp_path):
+    """`input_values` [1, T] -> `audio_codes` [1, F, n_q] i64 (onnx.rs:97-121): strided ELU conv stack, one self-attention block with LayerNorm, and a
+    residual vector quantiser written out in ONNX ops (distances by MatMul, ArgMin, Gather, Sub), against the same network in torch (f64).  The
+    seed is the first whose nearest / second-nearest codebook distances differ by more than f32 noise everywhere, so the codes are well defined."""
+    Tn, D, NQ, CB = 1920, 16, 3, 32
+    for seed in range(8, 40):
+        wav, P, ref, ref_res, margin = _codec_encoder_case(seed, Tn, D, NQ, CB)
+        if margin > 5e-3:
+            break
+    assert margin > 5e-3
+    inits = [W.tensor(k, v) for k, v in P.items() if k != "cb"] + [W.tensor("cb%d" % q, P["cb"][q]) for q in range(NQ)]
+    inits += [W.tensor("cbT%d" % q, np.ascontiguousarray(P["cb"][q].T)) for q in range(NQ)] + [W.tensor("cbn%d" % q, (P["cb"][q].astype(np.float64) ** 2).sum(1).astype(np.float32)) for q in range(NQ)]
+    inits += [W.tensor("ax1", np.asarray([1], np.int64)), W.tensor("ax2", np.asarray([2], np.int64)), W.tensor("scale", np.float32(1 / np.sqrt(D)).reshape(())),
+              W.tensor("two", np.float32(2).reshape(()))]
+    nodes = [
+        W.node("Unsqueeze", ["input_values", "ax1"], ["x"]),
+        W.node("Conv", ["x", "w1", "b1"], ["h1"], attrs=[W.attr_ints("pads", [3, 3])]), W.node("Elu", ["h1"], ["h1e"]),
+        W.node("Conv", ["h1e", "w2", "b2"], ["h2"], attrs=[W.attr_ints("strides", [4]), W.attr_ints("pads", [2, 2])]), W.node("Elu", ["h2"], ["h2e"]),
+        W.node("Conv", ["h2e", "w3", "b3"], ["h3"], attrs=[W.attr_ints("strides", [8]), W.attr_ints("pads", [4, 4])]),
+        W.node("Transpose", ["h3"], ["t"], attrs=[W.attr_ints("perm", [0, 2, 1])]),                                # [1, F, D]
+        W.node("LayerNormalization", ["t", "ln_g", "ln_b"], ["tn"], attrs=[W.attr_float("epsilon", 1e-5)]),
+        W.node("MatMul", ["tn", "wq"], ["q"]), W.node("MatMul", ["tn", "wk"], ["k"]), W.node("MatMul", ["tn", "wv"], ["v"]),
+        W.node("Transpose", ["k"], ["kT"], attrs=[W.attr_ints("perm", [0, 2, 1])]), W.node("MatMul", ["q", "kT"], ["sc"]), W.node("Mul", ["sc", "scale"], ["scs"]),
+        W.node("Softmax", ["scs"], ["pr"], attrs=[W.attr_int("axis", -1)]), W.node("MatMul", ["pr", "v"], ["ctx"]), W.node("MatMul", ["ctx", "wo"], ["att"]),
+        W.node("Add", ["t", "att"], ["res0"]),
+    ]
+    res = "res0"
+    for qn in range(NQ):  # residual VQ: argmin_c |r|^2 - 2 r.c + |c|^2  (the |r|^2 term does not change the argmin and is left out, as exporters do)
+        nodes += [W.node("MatMul", [res, "cbT%d" % qn], ["dot%d" % qn]), W.node("Mul", ["dot%d" % qn, "two"], ["dot2_%d" % qn]),
+                  W.node("Sub", ["cbn%d" % qn, "dot2_%d" % qn], ["dist%d" % qn]),
+                  W.node("ArgMin", ["dist%d" % qn], ["code%d" % qn], attrs=[W.attr_int("axis", -1), W.attr_int("keepdims", 1)]),
+                  W.node("Squeeze", ["code%d" % qn, "ax2"], ["codes%d" % qn]),
+                  W.node("Gather", ["cb%d" % qn, "codes%d" % qn], ["quant%d" % qn], attrs=[W.attr_int("axis", 0)]),
+                  W.node("Sub", [res, "quant%d" % qn], ["res%d" % (qn + 1)])]
+        res = "res%d" % (qn + 1)
+    nodes.append(W.node("Concat", ["code%d" % qn for qn in range(NQ)], ["audio_codes"], attrs=[W.attr_int("axis", 2)]))
+    F = ((Tn + 4 - 8) // 4 + 1 + 8 - 16) // 8 + 1
+    assert ref.shape == (1, F, NQ)
+    r = run_graph(gpu, tmp_path, nodes, inits, {"input_values": wav}, [("audio_codes", I64, [1, F, NQ]), (res, F32, [1, F, D])])
+    assert r["audio_codes"].shape == (1, F, NQ) and r["audio_codes"].dtype == np.int64
+    np.testing.assert_array_equal(r["audio_codes"], ref)
+    np.testing.assert_allclose(r[res], ref_res, rtol=1e-3, atol=2e-4)
+
+
+def test_unsupported_op_is_reported(gpu, tmp_path):
+    path = os.path.join(str(tmp_path), "u.onnx")
+    open(path, "wb").write(W.model([W.node("LSTM", ["x"], ["y"])], [], [W.value_info("x", F32, [1, 2])], [W.value_info("y", F32, [1, 2])]))
+    s = gpu.OnnxSession(path)
+    assert s.unsupported() == ["LSTM"] and not gpu.onnx_op_executable("LSTM") and gpu.onnx_op_executable("Conv")
+    with pytest.raises(RuntimeError, match="LSTM"):
+        s.run({"x": np.zeros((1, 2), np.float32)}, ["y"])
+    s.close()
+
+
+def _write_wav(path, samples_i16, rate, channels=1):
+    data = np.asarray(samples_i16, "<i2").tobytes()
+    with open(path, "wb") as f:
+        f.write(b"RIFF" + struct.pack("<I", 36 + len(data)) + b"WAVEfmt " + struct.pack("<IHHIIHH", 16, 1, channels, rate, rate * 2 * channels, 2 * channels, 16))
+        f.write(b"data" + struct.pack("<I", len(data)) + data)
+
+
+def test_create_voice_file_through_the_encoder_graphs(gpu, tiny_model, tmp_path):
+    """row a17 end to end: a model directory with `onnx/qwen3_tts_codec_encoder.onnx` + `onnx/qwen3_tts_speaker_encoder.onnx` (test-written graphs with the
+    reference's tensor names) makes TtsEngine::create_voice_file work (engine.rs:324-387: 24 kHz WAV -> audio_codes + 2048-d speaker embedding) and lets
+    `generate` start from raw reference audio, writing the `.cache` file (engine.rs:275-301).  Expected values: the same graphs through ctypes."""
+    rng = np.random.default_rng(11)
+    # --- codec encoder: input_values [1, T] -> audio_codes [1, F, 16]: two strided convs, then 16 "quantisers" = argmax over 16 slices of a projection
+    D, NQ, CB = 12, 16, 8
+    Pc = {"w1": (rng.standard_normal((8, 1, 9)) * 0.3).astype(np.float32), "b1": (rng.standard_normal(8) * 0.1).astype(np.float32),
+          "w2": (rng.standard_normal((D, 8, 16)) * 0.1).astype(np.float32), "b2": (rng.standard_normal(D) * 0.1).astype(np.float32),
+          "proj": (rng.standard_normal((D, NQ * CB)) * 0.5).astype(np.float32)}
+    cn = [W.node("Unsqueeze", ["input_values", "ax1"], ["x"]),
+          W.node("Conv", ["x", "w1", "b1"], ["h1"], attrs=[W.attr_ints("strides", [8]), W.attr_ints("pads", [4, 4])]), W.node("Elu", ["h1"], ["h1e"]),
+          W.node("Conv", ["h1e", "w2", "b2"], ["h2"], attrs=[W.attr_ints("strides", [16]), W.attr_ints("pads", [8, 7])]), W.node("Tanh", ["h2"], ["h2t"]),
+          W.node("Transpose", ["h2t"], ["t"], attrs=[W.attr_ints("perm", [0, 2, 1])]), W.node("MatMul", ["t", "proj"], ["lg"]),
+          W.node("Shape", ["lg"], ["lgs"]), W.node("Slice", ["lgs", "c0", "c2"], ["bf"]), W.node("Concat", ["bf", "qc"], ["ns"], attrs=[W.attr_int("axis", 0)]),
+          W.node("Reshape", ["lg", "ns"], ["lg4"]), W.node("ArgMax", ["lg4"], ["audio_codes"], attrs=[W.attr_int("axis", 3), W.attr_int("keepdims", 0)])]
+    ci = [W.tensor(k, v) for k, v in Pc.items()] + [W.tensor("ax1", np.asarray([1], np.int64)), W.tensor("c0", np.asarray([0], np.int64)),
+                                                   W.tensor("c2", np.asarray([2], np.int64)), W.tensor("qc", np.asarray([NQ, CB], np.int64))]
+    # --- speaker encoder: mels [1, n, 128] -> spk_emb [1, 2048]: conv + relu + mean / std pooling + linear
+    C = 16
+    Ps = {"w0": (rng.standard_normal((C, 128, 3)) * 0.05).astype(np.float32), "b0": (rng.standard_normal(C) * 0.1).astype(np.float32),
+          "fc": (rng.standard_normal((2048, 2 * C)) * 0.1).astype(np.float32), "fcb": (rng.standard_normal(2048) * 0.1).astype(np.float32)}
+    sn = [W.node("Transpose", ["mels"], ["x"], attrs=[W.attr_ints("perm", [0, 2, 1])]), W.node("Conv", ["x", "w0", "b0"], ["h"], attrs=[W.attr_ints("pads", [1, 1])]),
+          W.node("Relu", ["h"], ["hr"]), W.node("ReduceMean", ["hr"], ["mu"], attrs=[W.attr_ints("axes", [2]), W.attr_int("keepdims", 0)]),
+          W.node("Mul", ["hr", "hr"], ["h2"]), W.node("ReduceMean", ["h2"], ["m2"], attrs=[W.attr_ints("axes", [2]), W.attr_int("keepdims", 0)]),
+          W.node("Mul", ["mu", "mu"], ["mumu"]), W.node("Sub", ["m2", "mumu"], ["var"]), W.node("Relu", ["var"], ["varp"]), W.node("Sqrt", ["varp"], ["sd"]),
+          W.node("Concat", ["mu", "sd"], ["st"], attrs=[W.attr_int("axis", 1)]), W.node("Gemm", ["st", "fc", "fcb"], ["spk_emb"], attrs=[W.attr_int("transB", 1)])]
+    si = [W.tensor(k, v) for k, v in Ps.items()]
+    mdir = tmp_path / "model"
+    (mdir / "onnx").mkdir(parents=True)
+    for e in os.listdir(tiny_model):
+        if e != "onnx":
+            os.symlink(os.path.join(tiny_model, e), str(mdir / e))
+    for e in os.listdir(os.path.join(tiny_model, "onnx")):
+        os.symlink(os.path.join(tiny_model, "onnx", e), str(mdir / "onnx" / e))
+    enc_path, spk_path = str(mdir / "onnx" / "qwen3_tts_codec_encoder.onnx"), str(mdir / "onnx" / "qwen3_tts_speaker_encoder.onnx")
+    open(enc_path, "wb").write(W.model(cn, ci, [W.value_info("input_values", F32, [1, "T"])], [W.value_info("audio_codes", I64, [1, "F", 16])], opset=13))
+    open(spk_path, "wb").write(W.model(sn, si, [W.value_info("mels", F32, [1, "n", 128])], [W.value_info("spk_emb", F32, [1, 2048])], opset=13))
+    t = np.arange(24000 * 1) / 24000.0
+    pcm = (np.sin(2 * np.pi * 220 * t) * 0.4 + rng.standard_normal(t.size) * 0.05)
+    i16 = np.clip(np.round(pcm * 32767), -32768, 32767).astype(np.int16)
+    ref_wav, ref2_wav = str(tmp_path / "ref.wav"), str(tmp_path / "ref2.wav")
+    _write_wav(ref_wav, np.stack([i16, -i16], 1).reshape(-1), 24000, channels=2)   # stereo: create_voice_file keeps channel 0
+    _write_wav(ref2_wav, i16[:12000], 24000)
+    _write_wav(ref_wav + ".16k.wav", i16[:1000], 16000)
+    pkg = os.path.join(ROOT, "qwen3-tts-rust_amd")
+    exe = str(tmp_path / "voice_main")
+    subprocess.check_call(["g++", "-std=c++17", "-O1", "-o", exe, os.path.join(ROOT, "tests", "host", "voice_main.cpp"), "-L" + pkg, "-lq3tts_host", "-lq3tts",
+                           "-Wl,-rpath," + pkg])
+    vjson = str(tmp_path / "voice.json")
+    r = subprocess.run([exe, str(mdir), ref_wav, vjson, ref2_wav], capture_output=True, text=True, cwd=str(tmp_path))
+    assert r.returncode == 0 and r.stdout.strip().endswith("OK"), (r.stdout[-500:], r.stderr[-2000:])
+    v = json.load(open(vjson))
+    audio = (i16.astype(np.float32) / 32768.0)
+    s1 = gpu.OnnxSession(enc_path)
+    codes = s1.run({"input_values": audio[None, :]}, ["audio_codes"])["audio_codes"]
+    s1.close()
+    assert codes.shape[0] == 1 and codes.shape[2] == 16 and codes.min() >= 0 and codes.max() < CB and len(np.unique(codes)) > 2
+    assert v["audio_codes"] == codes.reshape(-1).tolist() and v["ref_text"] == "reference text"
+    s2 = gpu.OnnxSession(spk_path)
+    emb = s2.run({"mels": gpu.mel(audio)[None]}, ["spk_emb"])["spk_emb"]
+    s2.close()
+    got = np.asarray(v.get("speaker_embedding", v.get("spk_emb")), np.float32)
+    assert got.shape == (2048,) and np.isfinite(got).all() and np.abs(got).max() > 0
+    np.testing.assert_allclose(got, emb.reshape(-1), rtol=1e-6, atol=1e-7)
+    assert os.path.exists(str(tmp_path / "ref2.cache"))
