@@ -275,6 +275,15 @@ int q3tts_onnx_session_output_info(q3tts_onnx_session* s, const char* name, int3
 int q3tts_onnx_session_output(q3tts_onnx_session* s, const char* name, void* dst, int64_t cap_bytes); /* f32 or i64 elements */
 int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s);                              /* kernel launches of all runs so far */
 int q3tts_onnx_op_executable(const char* op_type);                                       /* 1 when the executor runs the op */
+/* AudioDecoder over the executor (/root/reference/src/models/onnx.rs:322-458): the exported streaming decoder graph with its state
+ * (pre_conv_history, latent_buffer, conv_history, past_key_i / past_value_i) carried on the device between chunks.  _decode returns the first
+ * `valid_samples` samples of `final_wav`; *n_out receives their count (call with pcm = NULL to learn it is at most cap: the chunk is consumed
+ * either way, so size pcm for the largest chunk: 1920 samples per frame for the reference's decoder). */
+typedef struct q3tts_onnx_decoder q3tts_onnx_decoder;
+int q3tts_onnx_decoder_open(const char* path, int32_t device, q3tts_onnx_decoder** out);
+void q3tts_onnx_decoder_close(q3tts_onnx_decoder* d);
+int q3tts_onnx_decoder_reset(q3tts_onnx_decoder* d);
+int q3tts_onnx_decoder_decode(q3tts_onnx_decoder* d, const int64_t* codes, int32_t n_frames, int32_t is_final, float* pcm, int64_t cap, int64_t* n_out);
 
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,

@@ -338,3 +338,29 @@ int q3tts_onnx_session_output(q3tts_onnx_session* s, const char* name, void* dst
 int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s) { return s ? (int64_t)s->s->launches() : 0; }
 int q3tts_onnx_op_executable(const char* op_type) { return op_type && q3::onnx_exec_supports(op_type) ? 1 : 0; }
 }
+struct q3tts_onnx_decoder { std::unique_ptr<q3::OnnxStreamDecoder> d; };
+extern "C" {
+int q3tts_onnx_decoder_open(const char* path, int32_t device, q3tts_onnx_decoder** out) {
+    try {
+        if (!path || !out) throw q3::Error("q3tts_onnx_decoder_open: null argument");
+        auto* h = new q3tts_onnx_decoder();
+        try { h->d.reset(new q3::OnnxStreamDecoder(path, device)); } catch (...) { delete h; throw; }
+        *out = h;
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+void q3tts_onnx_decoder_close(q3tts_onnx_decoder* d) { delete d; }
+int q3tts_onnx_decoder_reset(q3tts_onnx_decoder* d) {
+    try { if (!d) throw q3::Error("null decoder"); d->d->reset(); return 0; } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int q3tts_onnx_decoder_decode(q3tts_onnx_decoder* d, const int64_t* codes, int32_t n_frames, int32_t is_final, float* pcm, int64_t cap, int64_t* n_out) {
+    try {
+        if (!d || !n_out) throw q3::Error("q3tts_onnx_decoder_decode: null argument");
+        const std::vector<float> v = d->d->decode(codes, n_frames, is_final != 0);
+        *n_out = (int64_t)v.size();
+        if ((int64_t)v.size() > cap || (!pcm && !v.empty())) throw q3::Error("pcm buffer too small for the chunk (" + std::to_string(v.size()) + " samples)");
+        if (!v.empty()) memcpy(pcm, v.data(), v.size() * 4);
+        return 0;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+}

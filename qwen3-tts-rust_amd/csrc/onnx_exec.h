@@ -36,6 +36,8 @@ public:
     // op types of the graph this executor cannot run (empty = the graph is executable)
     std::vector<std::string> unsupported_ops() const;
     void set_input(const std::string& name, int dtype, const void* data, const std::vector<int64_t>& shape);
+    void bind_input(const std::string& name, const XTensor& t);     // a tensor already on the device (state fed back from a previous run)
+    XTensor zeros(int dtype, const std::vector<int64_t>& shape);    // device tensor of zeros (any dimension may be 0)
     void run();                                                    // throws q3::Error naming the node on failure
     const XTensor& value(const std::string& name) const;           // any graph edge after run() (outputs stay alive)
     void fetch(const XTensor& t, void* dst, size_t cap_bytes) const; // f32 / bool -> float, i64 -> int64_t
@@ -50,5 +52,21 @@ private:
 
 // true when this executor has a kernel (or a host evaluation) for the op type
 bool onnx_exec_supports(const std::string& op_type);
+
+// AudioDecoder over a session (/root/reference/src/models/onnx.rs:322-458): the exported streaming decoder takes `audio_codes [1, N, 16]`, `is_last [1]`
+// and the state tensors `pre_conv_history`, `latent_buffer`, `conv_history`, `past_key_i` / `past_value_i` (i = 0..7) and returns `final_wav`,
+// `valid_samples` and the `next_*` state.  The state starts with zero-length time axes (DecoderState::new, onnx.rs:470-495) and stays on the device
+// between chunks.  This is the general (one launch per node) route for the exported graph; the engine's own codec kernels are the fast route.
+class OnnxStreamDecoder {
+public:
+    OnnxStreamDecoder(const std::string& path, int device);
+    void reset();
+    std::vector<float> decode(const int64_t* codes, int n_frames, bool is_final);   // AudioDecoder::decode, onnx.rs:341-458
+    OnnxSession& session() { return s_; }
+private:
+    OnnxSession s_;
+    std::vector<std::pair<std::string, std::string>> state_io_; // (input name, output name)
+    std::map<std::string, XTensor> state_;
+};
 
 } // namespace q3

@@ -610,6 +610,13 @@ void OnnxSession::set_input(const std::string& name, int dtype, const void* data
     if (t.numel()) Q3_HIP(hipMemcpy(t.dev->p, data, (size_t)t.numel() * t.esize(), hipMemcpyHostToDevice));
     impl_->inputs[name] = t;
 }
+void OnnxSession::bind_input(const std::string& name, const XTensor& t) { impl_->inputs[name] = t; }
+XTensor OnnxSession::zeros(int dtype, const std::vector<int64_t>& shape) {
+    Q3_HIP(hipSetDevice(device_));
+    XTensor t = impl_->dev_tensor(dtype, shape);
+    if (t.numel()) Q3_HIP(hipMemset(t.dev->p, 0, (size_t)t.numel() * t.esize()));
+    return t;
+}
 const XTensor& OnnxSession::value(const std::string& name) const {
     auto it = impl_->vals.find(name);
     if (it == impl_->vals.end()) throw Error("no value named " + name + " (run() first; only graph outputs and live edges are kept)");
@@ -1161,6 +1168,53 @@ void OnnxSession::run() {
     }
     Q3_HIP(hipDeviceSynchronize());
     for (auto& o : model_->outputs) if (!I.vals.count(o.name)) throw Error("graph output " + o.name + " was not produced");
+}
+
+OnnxStreamDecoder::OnnxStreamDecoder(const std::string& path, int device) : s_(path, device) {
+    const std::string miss = s_.model().check_decoder_contract();
+    if (!miss.empty()) throw Error("not a streaming decoder graph (onnx.rs:355-455): missing" + miss);
+    const auto bad = s_.unsupported_ops();
+    if (!bad.empty()) { std::string t; for (auto& b : bad) t += " " + b; throw Error("the decoder graph uses operators without a kernel:" + t); }
+    for (const char* n : {"pre_conv_history", "latent_buffer", "conv_history"}) state_io_.push_back({n, std::string("next_") + n});
+    for (int i = 0; i < 8; i++) { state_io_.push_back({"past_key_" + std::to_string(i), "next_key_" + std::to_string(i)}); state_io_.push_back({"past_value_" + std::to_string(i), "next_value_" + std::to_string(i)}); }
+    reset();
+}
+void OnnxStreamDecoder::reset() {
+    // DecoderState::new (onnx.rs:470-495): every state tensor starts with a zero-length time axis.  The static dimensions come from the graph's declared
+    // input shapes (symbolic / unknown dimensions -> 0); the reference's constants are the fallback when a graph declares no shape.
+    state_.clear();
+    for (auto& io : state_io_) {
+        std::vector<int64_t> shape;
+        for (const auto& vi : s_.model().inputs) if (vi.name == io.first) { shape = vi.shape; break; }
+        if (shape.empty()) {
+            if (io.first == "pre_conv_history") shape = {1, 512, -1};
+            else if (io.first == "latent_buffer" || io.first == "conv_history") shape = {1, 1024, -1};
+            else shape = {1, 16, -1, 64};
+        }
+        for (auto& d : shape) if (d < 0) d = 0;
+        state_[io.first] = s_.zeros(1, shape);
+    }
+}
+std::vector<float> OnnxStreamDecoder::decode(const int64_t* codes, int n_frames, bool is_final) {
+    if (n_frames <= 0) return {};                                           // onnx.rs:350-353
+    Q3_CHECK(codes != nullptr, "null codes");
+    s_.set_input("audio_codes", 7, codes, {1, (int64_t)n_frames, 16});
+    const float last = is_final ? 1.0f : 0.0f;
+    s_.set_input("is_last", 1, &last, {1});
+    for (auto& kv : state_) s_.bind_input(kv.first, kv.second);
+    s_.run();
+    const XTensor& wav = s_.value("final_wav");
+    std::vector<float> pcm((size_t)wav.numel());
+    s_.fetch(wav, pcm.data(), pcm.size() * 4);
+    const XTensor& vs = s_.value("valid_samples");
+    Q3_CHECK(vs.numel() >= 1, "valid_samples is empty");
+    int64_t valid = 0;
+    if (vs.dtype == 7) { std::vector<int64_t> v((size_t)vs.numel()); s_.fetch(vs, v.data(), v.size() * 8); valid = v[0]; }
+    else { std::vector<float> v((size_t)vs.numel()); s_.fetch(vs, v.data(), v.size() * 4); valid = (int64_t)v[0]; }
+    if (valid < 0) valid = 0;
+    if ((size_t)valid < pcm.size()) pcm.resize((size_t)valid);              // `.take(valid_count)`
+    for (auto& io : state_io_) state_[io.first] = s_.value(io.second);      // updated unconditionally, as the reference does
+    return pcm;
 }
 
 } // namespace q3

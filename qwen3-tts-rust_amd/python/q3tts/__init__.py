@@ -72,6 +72,7 @@ SYMBOLS = [
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
     "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
     "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
+    "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
@@ -620,6 +621,35 @@ class OnnxSession:
 
     def launches(self):
         return lib().q3tts_onnx_session_launches(self.h)
+
+
+class OnnxDecoder:
+    """The exported streaming decoder graph run through the executor with its state on the device (AudioDecoder, onnx.rs:322-458)"""
+
+    def __init__(self, path, device=0):
+        L = lib()
+        L.q3tts_onnx_decoder_open.argtypes = [C.c_char_p, C.c_int32, C.POINTER(C.c_void_p)]
+        L.q3tts_onnx_decoder_close.argtypes = [C.c_void_p]
+        L.q3tts_onnx_decoder_reset.argtypes = [C.c_void_p]
+        L.q3tts_onnx_decoder_decode.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+        h = C.c_void_p()
+        _chk(L.q3tts_onnx_decoder_open(path.encode(), device, C.byref(h)))
+        self.h = h.value
+
+    def close(self):
+        if self.h:
+            lib().q3tts_onnx_decoder_close(self.h)
+        self.h = None
+
+    def reset(self):
+        _chk(lib().q3tts_onnx_decoder_reset(self.h))
+
+    def decode(self, codes, is_final=False, max_samples_per_frame=1920):
+        codes = np.ascontiguousarray(codes, np.int64).reshape(-1, 16)
+        out = np.zeros(max(codes.shape[0], 1) * max_samples_per_frame, np.float32)
+        n = C.c_int64()
+        _chk(lib().q3tts_onnx_decoder_decode(self.h, codes.ctypes.data, codes.shape[0], 1 if is_final else 0, out.ctypes.data, out.size, C.byref(n)))
+        return out[: n.value].copy()
 
 
 def onnx_op_executable(op_type):

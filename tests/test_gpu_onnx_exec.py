@@ -488,3 +488,91 @@ def test_create_voice_file_through_the_encoder_graphs(gpu, tiny_model, tmp_path)
     assert got.shape == (2048,) and np.isfinite(got).all() and np.abs(got).max() > 0
     np.testing.assert_allclose(got, emb.reshape(-1), rtol=1e-6, atol=1e-7)
     assert os.path.exists(str(tmp_path / "ref2.cache"))
+
+
+def test_streaming_decoder_contract_over_the_executor(gpu, tmp_path):
+    """The exported decoder's I/O contract (onnx.rs:341-458): `audio_codes`, `is_last` and zero-length-initialised state tensors in, `final_wav`,
+    `valid_samples` and `next_*` out, state carried on the device between chunks.  The graph here is a small causal network written for the test
+    (embedding sum, causal conv with `pre_conv_history`, a running mean through `past_key_0`, a second causal conv with `conv_history`, transposed-conv
+    upsampling; its pads, slices and ranges are computed from Shape nodes as exporters do).  Chunked decoding must equal a numpy model of the whole
+    sequence, trimmed per chunk by `valid_samples`."""
+    rng = np.random.default_rng(21)
+    D, V = 8, 32
+    table = rng.standard_normal((V, D)).astype(np.float32) * 0.3
+    wc = rng.standard_normal((D, D, 3)).astype(np.float32) * 0.2
+    w2 = rng.standard_normal((D, D, 2)).astype(np.float32) * 0.2
+    wt = rng.standard_normal((D, 1, 4)).astype(np.float32) * 0.3
+    I = lambda name, v: W.tensor(name, np.asarray(v, np.int64))
+    inits = [W.tensor("table", table), W.tensor("wc", wc), W.tensor("w2", w2), W.tensor("wt", wt), I("ax2", [2]), I("i0", 0), I("i1", 1), I("i2", 2), I("i4", 4), I("z1", [0]),
+             I("zz", [0, 0]), I("zzz", [0, 0, 0]), I("m2", [-2]), I("m1", [-1]), I("m3", [-3]), I("big", [2 ** 62]), I("axk", [2]), I("shp_k", [1, -1, 2, 4]), I("shp_m", [1, -1, D]),
+             I("shp_c", [1, 1, -1, 1]), W.tensor("halff", np.float32(0.5).reshape(())), W.tensor("twof", np.float32(2).reshape(()))]
+    n = W.node
+    nodes = [
+        n("Gather", ["table", "audio_codes"], ["emb"]), n("ReduceSum", ["emb", "ax2"], ["x0"], attrs=[W.attr_int("keepdims", 0)]),
+        n("Transpose", ["x0"], ["x"], attrs=[W.attr_ints("perm", [0, 2, 1])]),
+        # causal conv (k = 3) with history
+        n("Concat", ["pre_conv_history", "x"], ["cat1"], attrs=[W.attr_int("axis", 2)]),
+        n("Shape", ["pre_conv_history"], ["s1"]), n("Gather", ["s1", "i2"], ["h1"]), n("Sub", ["i2", "h1"], ["p1"]), n("Unsqueeze", ["p1", "z1"], ["p1u"]),
+        n("Concat", ["zz", "p1u", "zzz"], ["pads1"], attrs=[W.attr_int("axis", 0)]), n("Pad", ["cat1", "pads1"], ["pad1"]),
+        n("Conv", ["pad1", "wc"], ["y"]), n("Slice", ["pad1", "m2", "big", "ax2"], ["next_pre_conv_history"]),
+        # running mean over everything seen so far, through the key cache of layer 0
+        n("Transpose", ["y"], ["yt"], attrs=[W.attr_ints("perm", [0, 2, 1])]), n("Reshape", ["yt", "shp_k"], ["k4"]),
+        n("Transpose", ["k4"], ["knew"], attrs=[W.attr_ints("perm", [0, 2, 1, 3])]),
+        n("Concat", ["past_key_0", "knew"], ["next_key_0"], attrs=[W.attr_int("axis", 2)]),
+        n("Mul", ["knew", "twof"], ["vnew"]), n("Concat", ["past_value_0", "vnew"], ["next_value_0"], attrs=[W.attr_int("axis", 2)]),
+        n("CumSum", ["next_key_0", "i2"], ["cs"]),
+        n("Shape", ["audio_codes"], ["sc"]), n("Gather", ["sc", "i1"], ["N"]), n("Neg", ["N"], ["negN"]), n("Unsqueeze", ["negN", "z1"], ["negNu"]),
+        n("Slice", ["cs", "negNu", "big", "axk"], ["csn"]),
+        n("Shape", ["next_key_0"], ["sk"]), n("Gather", ["sk", "i2"], ["total"]), n("Sub", ["total", "N"], ["t0"]), n("Add", ["t0", "i1"], ["r0"]), n("Add", ["total", "i1"], ["r1"]),
+        n("Range", ["r0", "r1", "i1"], ["cnt"]), n("Cast", ["cnt"], ["cntf"], attrs=[W.attr_int("to", 1)]), n("Reshape", ["cntf", "shp_c"], ["cnt4"]),
+        n("Div", ["csn", "cnt4"], ["mean4"]), n("Transpose", ["mean4"], ["mean4t"], attrs=[W.attr_ints("perm", [0, 2, 1, 3])]), n("Reshape", ["mean4t", "shp_m"], ["mean3"]),
+        n("Transpose", ["mean3"], ["m"], attrs=[W.attr_ints("perm", [0, 2, 1])]), n("Add", ["y", "m"], ["z"]),
+        # latent buffer: the last three frames, carried only
+        n("Concat", ["latent_buffer", "z"], ["lat"], attrs=[W.attr_int("axis", 2)]), n("Slice", ["lat", "m3", "big", "ax2"], ["next_latent_buffer"]),
+        # second causal conv (k = 2) with its own history
+        n("Concat", ["conv_history", "z"], ["cat2"], attrs=[W.attr_int("axis", 2)]),
+        n("Shape", ["conv_history"], ["s2"]), n("Gather", ["s2", "i2"], ["h2"]), n("Sub", ["i1", "h2"], ["p2"]), n("Unsqueeze", ["p2", "z1"], ["p2u"]),
+        n("Concat", ["zz", "p2u", "zzz"], ["pads2"], attrs=[W.attr_int("axis", 0)]), n("Pad", ["cat2", "pads2"], ["pad2"]),
+        n("Conv", ["pad2", "w2"], ["u"]), n("Slice", ["pad2", "m1", "big", "ax2"], ["next_conv_history"]),
+        n("ConvTranspose", ["u", "wt"], ["up"], attrs=[W.attr_ints("strides", [4])]), n("Tanh", ["up"], ["final_wav"]),
+        # valid_samples: everything on the last chunk, two samples held back otherwise
+        n("Mul", ["N", "i4"], ["full"]), n("Sub", ["full", "i2"], ["held"]), n("Unsqueeze", ["full", "z1"], ["fullu"]), n("Unsqueeze", ["held", "z1"], ["heldu"]),
+        n("Greater", ["is_last", "halff"], ["lastb"]), n("Where", ["lastb", "fullu", "heldu"], ["valid_samples"]),
+    ]
+    ins = [W.value_info("audio_codes", I64, [1, "N", 16]), W.value_info("is_last", F32, [1]), W.value_info("pre_conv_history", F32, [1, D, "h"]),
+           W.value_info("latent_buffer", F32, [1, D, "l"]), W.value_info("conv_history", F32, [1, D, "c"])]
+    outs = [W.value_info("final_wav", F32, [1, 1, "S"]), W.value_info("valid_samples", I64, [1]), W.value_info("next_pre_conv_history", F32, [1, D, 2]),
+            W.value_info("next_latent_buffer", F32, [1, D, "l2"]), W.value_info("next_conv_history", F32, [1, D, 1])]
+    for i in range(8):
+        ins += [W.value_info("past_key_%d" % i, F32, [1, 2, "t", 4]), W.value_info("past_value_%d" % i, F32, [1, 2, "t", 4])]
+        outs += [W.value_info("next_key_%d" % i, F32, [1, 2, "t2", 4]), W.value_info("next_value_%d" % i, F32, [1, 2, "t2", 4])]
+        if i > 0:
+            nodes += [n("Identity", ["past_key_%d" % i], ["next_key_%d" % i]), n("Identity", ["past_value_%d" % i], ["next_value_%d" % i])]
+    path = str(tmp_path / "dec.onnx")
+    open(path, "wb").write(W.model(nodes, inits, ins, outs, opset=13))
+    m = gpu.OnnxModel(path)
+    assert m.decoder_contract() == (True, "") or m.decoder_contract()[0] is True
+    m.close()
+    T = 11
+    codes = rng.integers(0, V, (T, 16))
+    # numpy model of the whole sequence
+    x = table[codes].sum(1).T.astype(np.float64)                                    # [D, T]
+    xp = np.concatenate([np.zeros((D, 2)), x], 1)
+    y = np.stack([sum(wc[:, :, k].astype(np.float64) @ xp[:, t + k] for k in range(3)) for t in range(T)], 1)
+    mean = np.cumsum(y, 1) / np.arange(1, T + 1)
+    z = y + mean
+    zp = np.concatenate([np.zeros((D, 1)), z], 1)
+    u = np.stack([sum(w2[:, :, k].astype(np.float64) @ zp[:, t + k] for k in range(2)) for t in range(T)], 1)
+    wav = np.tanh(np.einsum("dt,dj->tj", u, wt[:, 0, :].astype(np.float64)).reshape(-1))   # [4 T]
+    dec = gpu.OnnxDecoder(path)
+    for chunks in ([3, 4, 1, 3], [11], [1] * 11):
+        dec.reset()
+        got, exp, at = [], [], 0
+        for ci, c in enumerate(chunks):
+            last = ci == len(chunks) - 1
+            pcm = dec.decode(codes[at:at + c], is_final=last, max_samples_per_frame=4)
+            assert pcm.size == (4 * c if last else 4 * c - 2)
+            got.append(pcm); exp.append(wav[4 * at: 4 * at + pcm.size]); at += c
+        np.testing.assert_allclose(np.concatenate(got), np.concatenate(exp), rtol=2e-4, atol=2e-5, err_msg=str(chunks))
+    assert dec.decode(np.zeros((0, 16), np.int64)).size == 0                         # n_frames == 0 -> empty (onnx.rs:350-353)
+    dec.close()
