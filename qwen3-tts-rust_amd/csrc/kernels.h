@@ -63,8 +63,9 @@ struct KvCache {           // paged f16 KV cache (pages of 64 positions)
 // out[(sseg*ntok + tok)*out_stride + r] = super-segment partial of row (row0+r) . x[tok]      (spec S3)
 // batched steps: gate/up GEMM on the matrix cores with the SwiGLU + quantisation epilogue; false = shape not supported (caller falls back)
 bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok);
+struct NormTail;   // norm_tail.h: the consumer's residual + RMSNorm + quantisation, run by the last workgroups of the GEMM (*tail_fused says whether it was)
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
-                    float* out, int out_stride, int ntok, int lpr_hint = 0);
+                    float* out, int out_stride, int ntok, int lpr_hint = 0, const NormTail* tail = nullptr, bool* tail_fused = nullptr);
 
 // h = h_in (+ sum of nparts partial slabs, in order); optional store h_out; xn = rmsnorm(h)*g (spec S4);
 // quantise to int8 blocks (spec S2).  h_in may be indirect: row idx[tok] of a table (idx != nullptr).

@@ -13,6 +13,7 @@
 #include "../../include/q3tts_spec.h"
 #include "kdev.h"
 #include "wslice.h"
+#include "norm_tail.h"
 
 namespace q3 {
 
@@ -91,7 +92,7 @@ __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __rest
 #define Q3_GEMM_Q8_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <bool GU, bool SM>
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad, NormTail tail);
 template <bool GU, int ABL = 0>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
@@ -228,7 +229,8 @@ static void gemv_launch_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, 
     else gemv_launch<LPR, 8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
 }
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
-                    float* out, int out_stride, int ntok, int lpr_hint) {
+                    float* out, int out_stride, int ntok, int lpr_hint, const NormTail* tail, bool* tail_fused) {
+    if (tail_fused) *tail_fused = false;
     const int nsseg = ((w.K >> 8) + 7) / 8;
     if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
         int lpr = lpr_hint;
@@ -256,12 +258,14 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
                                out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
             return;
         }
+        NormTail nt{};
+        if (tail && tail->counters && 64 * nw >= 64 * (tail->d >> 8) && (tail->d & 255) == 0 && tail->d <= 2048 && !tail->a.idx_keys) { nt = *tail; if (tail_fused) *tail_fused = true; }
         if (q8_scale_mfma())
             hipLaunchKernelGGL((k_gemm_q8_mfma<false, true>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr, nt);
         else
             hipLaunchKernelGGL((k_gemm_q8_mfma<false, false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr, nt);
         return;
     }
     if (ntok > 8 && !lpr_hint) {
@@ -297,8 +301,8 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
     }
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-    if (q8_scale_mfma()) hipLaunchKernelGGL((k_gemm_q8_mfma<true, true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
-    else hipLaunchKernelGGL((k_gemm_q8_mfma<true, false>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    if (q8_scale_mfma()) hipLaunchKernelGGL((k_gemm_q8_mfma<true, true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad, NormTail{});
+    else hipLaunchKernelGGL((k_gemm_q8_mfma<true, false>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad, NormTail{});
     return true;
 }
 
@@ -399,8 +403,8 @@ typedef float f32x32q __attribute__((ext_vector_type(32)));
 template <bool GU, bool SM>
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
-                                                      int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
-    __shared__ float red[8][32][33];
+                                                      int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad, NormTail tail) {
+    __shared__ __attribute__((aligned(16))) float red[8][32][33];
     __shared__ __attribute__((aligned(16))) float sc_s[8][2][8][16]; // [wave][lane half][block][accumulator reg]: activation scales, widened to f32 once
     __shared__ float gate_s[GU ? 4 : 1][GU ? 1024 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -515,6 +519,7 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
             __syncthreads(); // red / sc_s are rewritten by the next tile
         }
     }
+    if (!GU) norm_tail(tail, ntok, reinterpret_cast<unsigned char*>(&red[0][0][0])); // the consumer's residual + RMSNorm + quant (norm_tail.h)
 }
 
 // -----------------------------------------------------------------------------------------------------

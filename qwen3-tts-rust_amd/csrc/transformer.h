@@ -90,6 +90,8 @@ private:
     void alloc_workspace();
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
+    DevBuf<unsigned> tail_counters_; // norm_tail.h: ticket + done counters of the GEMM-tail norms (zero between launches)
+    bool norm_tail_ = false;         // Q3_NORM_TAIL=1: the batched path's norms run as GEMM tails (norm_tail.h; measured 2 x SLOWER: device-scope fences)
     bool same_seq_ = false; bool short_ctx_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
     std::map<const uint8_t*, uint8_t*>& mat_meta_ = ws_->mat_meta; std::map<const uint8_t*, uint8_t*>& mat_types_ = ws_->mat_types; std::map<const uint8_t*, uint32_t*>& mat_off_ = ws_->mat_off;
     DevBuf<int8_t> xq_, aq_, fq_;
