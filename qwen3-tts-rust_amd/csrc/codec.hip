@@ -269,11 +269,12 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 // (BN = 64 wastes a quarter of the matrix work at N = 96) and the activation tile is fetched once per 96 output columns instead of once per 64.
 // One K tile in flight and ~110 VGPRs / 36 KB of LDS keep 4 workgroups per CU -- the middle ground between k_conv_gemm_h<1> (8 per CU, the
 // L2 -> LDS traffic 2.3 x larger) and k_conv_gemm_h2<2, 3> (2 per CU, spills).  Reads pre-split operands as copies.
-template <int MR, int NT>
+template <int MR, int NT, int BK>
 __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
-    constexpr int BM = 128 * MR, BN = 32 * NT, BK = 32, LD = 40;
-    constexpr int NA = BM * 8 / 256;
-    constexpr int NB = (BN * 4 + 255) / 256;
+    constexpr int BM = 128 * MR, BN = 32 * NT, LD = BK + 8; // LD: padded row stride (f16); 80 / 144 B keep the b128 fragment reads conflict-free
+    constexpr int KQ = BK / 4, KC = BK / 8;                  // float4 pieces of an A row, uint4 pieces of a B row per K tile
+    constexpr int NA = BM * KQ / 256;
+    constexpr int NB = (BN * KC + 255) / 256;
     __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
     __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
     __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
@@ -292,21 +293,21 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     uint4 rh[NB], rl[NB];
     int arow[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
+    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / KQ; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            const int e = tid + i * 256, r = e / KQ, kq = e % KQ;
             ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
             if (m0 + r < g.M) ra[i] = g.a_split ? load_a4_split_raw(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * kq)
                                                 : *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
+            const int e = tid + i * 256, r = e / KC, wk = 8 * (e % KC);
             rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
-            if (e < BN * 4 && n0 + r < g.N) {
+            if (e < BN * KC && n0 + r < g.N) {
                 rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
                 rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
             }
@@ -315,7 +316,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / 8, kq = e % 8;
+            const int e = tid + i * 256, r = e / KQ, kq = e % KQ;
             if (g.a_split) {
                 *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(ra[i].x, ra[i].y);
                 *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(ra[i].z, ra[i].w);
@@ -330,8 +331,8 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
+            const int e = tid + i * 256, r = e / KC, wk = 8 * (e % KC);
+            if (e < BN * KC) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
         }
     };
     fetch(kbeg);
@@ -759,8 +760,12 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
         static const int h3_nt6 = [] { const char* e = std::getenv("Q3_CODEC_H3_NT6"); return e ? atoi(e) : 0; }(); // workgroups from which N % 192 == 0 uses 192-column tiles
         if (h3_nt6 > 0 && (g.N / 96) * ((g.M + 255) / 256) >= h3_nt6) // "NT6" knob reused: workgroups from which the 256-row tile is used
-            hipLaunchKernelGGL((k_conv_gemm_h3<2, 3>), dim3(g.N / 96, (g.M + 255) / 256, 1), dim3(256), 0, st, g, wh, wl);
-        else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+            hipLaunchKernelGGL((k_conv_gemm_h3<2, 3, 32>), dim3(g.N / 96, (g.M + 255) / 256, 1), dim3(256), 0, st, g, wh, wl);
+        else {
+            static const int h3_bk64 = [] { const char* e = std::getenv("Q3_CODEC_H3_BK64"); return e ? atoi(e) : 0; }(); // K from which the 64-deep K tile is used (0 = never)
+            if (h3_bk64 > 0 && g.cin % 64 == 0 && g.K >= h3_bk64) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 64>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+            else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+        }
         return;
     }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
