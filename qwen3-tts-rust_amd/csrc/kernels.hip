@@ -119,9 +119,9 @@ static int mfma2_ztiles(int rowgroups, int nsseg, int ntok) {
 }
 __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                               float* __restrict__ out, int out_stride, int ntok);
-template <int TYPE>
-__global__ void k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x, int x_stride, float* __restrict__ out,
-                                  int out_stride, int ntok);
+template <int TYPE, int WPE> // WPE = waves per SIMD the register budget is cut for: 4 = 128 VGPRs (spills 200 B per lane, 2 workgroups per CU), 2 = 256 VGPRs (no spill, 1 per CU)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x, int x_stride, float* __restrict__ out, int out_stride, int ntok);
 void init_fused_kernel_attributes();
 // dynamic-LDS opt-ins (per device): done once at engine construction so that no attribute call happens inside a stream capture
 void init_kernel_attributes() {
@@ -131,9 +131,12 @@ void init_kernel_attributes() {
     if (dev < 0 || dev > 63 || done[dev]) return;
     Q3_HIP(hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     constexpr int lds = Q3_SSEG_SEGS * 64 * 33 * (int)sizeof(float); // k_gemm_float_mfma: [8 segments][64 rows][FM_PAD]
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     init_fused_kernel_attributes();
     done[dev] = true;
 }
@@ -1339,8 +1342,8 @@ __device__ __forceinline__ void unpack_raw(const RawChunk<TYPE>& r, float* v) {
     }
 }
 constexpr int FM_TOK = 32, FM_PAD = 33; // tokens per workgroup tile; LDS row pitch (conflict-free transposed read)
-template <int TYPE>
-__global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
+template <int TYPE, int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
                                                          int x_stride, float* __restrict__ out, int out_stride, int ntok) {
     extern __shared__ float segsum[]; // [8 segments][64 rows][FM_PAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1365,29 +1368,27 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict_
             const float* xp = xrow + (s << 8);
             // operands are fetched one block ahead.  Two blocks ahead for the weights (DEEP) measured slower on MI355X: 200 vs 157 us
             // for the 12288 x 2048 x 256-token prefill GEMM -- the extra live registers cost more than the latency they hide.
-            constexpr bool DEEP = false;
-            RawChunk<TYPE> raw[4], raw1[4];
+            RawChunk<TYPE> raw[4];
             float4 xb[8];
 #pragma unroll
-            for (int j = 0; j < 4; j++) { raw[j] = load_raw<TYPE>(wp + (size_t)j * CH); if constexpr (DEEP) raw1[j] = load_raw<TYPE>(wp + (size_t)(4 + j) * CH); }
+            for (int j = 0; j < 4; j++) raw[j] = load_raw<TYPE>(wp + (size_t)j * CH);
 #pragma unroll
             for (int j = 0; j < 8; j++) xb[j] = *reinterpret_cast<const float4*>(xp + 4 * j);
 #pragma unroll 1
             for (int b = 0; b < 8; b++) {
-                const int b1 = b < 7 ? b + 1 : 7, b2 = b < 6 ? b + 2 : 7; // (the tail re-reads the last block; unused)
-                RawChunk<TYPE> raw2[4];
-                float4 xn[8];
-                // (activations first: vmcnt retires in issue order, so waiting for them must not also wait for the far weight block)
-#pragma unroll
-                for (int j = 0; j < 8; j++) xn[j] = *reinterpret_cast<const float4*>(xp + b1 * 32 + 4 * j);
-#pragma unroll
-                for (int j = 0; j < 4; j++) raw2[j] = load_raw<TYPE>(wp + (size_t)((DEEP ? b2 : b1) * 4 + j) * CH);
+                const int b1 = b < 7 ? b + 1 : 7; // (the tail re-reads the last block; unused)
+                // Rolling prefetch: as soon as chunk j of this block has been multiplied, its registers take chunk j of the NEXT block (weights and
+                // activations), three quarters of a block ahead of their use.  The earlier form held a whole second set (next weights + next
+                // activations: 48 more VGPRs) next to four 32-register accumulators and spilled 200 B per lane inside this loop.
                 f32x32 p01, p23;
 #pragma unroll
                 for (int j = 0; j < 4; j++) {
                     float wv[8];
                     unpack_raw<TYPE>(raw[j], wv);
                     const float xv[8] = { xb[2 * j].x, xb[2 * j].y, xb[2 * j].z, xb[2 * j].w, xb[2 * j + 1].x, xb[2 * j + 1].y, xb[2 * j + 1].z, xb[2 * j + 1].w };
+                    xb[2 * j] = *reinterpret_cast<const float4*>(xp + b1 * 32 + 8 * j);
+                    xb[2 * j + 1] = *reinterpret_cast<const float4*>(xp + b1 * 32 + 8 * j + 4);
+                    raw[j] = load_raw<TYPE>(wp + (size_t)(b1 * 4 + j) * CH);
                     f32x32 c;
 #pragma unroll
                     for (int v = 0; v < 32; v++) c[v] = 0.0f;
@@ -1396,10 +1397,6 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma(const void* __restrict_
                     if (j == 0) p01 = c; else if (j == 1) p01 = p01 + c; else if (j == 2) p23 = c; else p23 = p23 + c;
                 }
                 acc = acc + (p01 + p23);
-#pragma unroll
-                for (int j = 0; j < 4; j++) { if constexpr (DEEP) { raw[j] = raw1[j]; raw1[j] = raw2[j]; } else raw[j] = raw2[j]; }
-#pragma unroll
-                for (int j = 0; j < 8; j++) xb[j] = xn[j];
             }
             float* dst = segsum + (size_t)wave * 64 * FM_PAD;
 #pragma unroll
@@ -1616,7 +1613,9 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
         return true;
     }
     dim3 grid(xcd_grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK));
-    hipLaunchKernelGGL((k_gemm_float_mfma<TYPE>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+    static const bool wide_regs = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WPE2"); return e ? e[0] == '1' : true; }(); // default: the 256-VGPR build (no spills)
+    if (wide_regs) hipLaunchKernelGGL((k_gemm_float_mfma<TYPE, 2>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+    else hipLaunchKernelGGL((k_gemm_float_mfma<TYPE, 4>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
     return true;
 }
 // fused gate/up + SwiGLU for batched steps; false = not applicable (caller runs the matmul and k_swiglu_f32)
