@@ -140,6 +140,11 @@ void init_kernel_attributes() {
     init_fused_kernel_attributes();
     done[dev] = true;
 }
+static bool kq_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_KQ_MFMA"); return e ? e[0] == '1' : true; }(); return on; } // 0: K-quant batches through the z-tiled GEMV
+template <bool GU, int TS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
+               int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
 static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
@@ -235,6 +240,13 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
                     float* out, int out_stride, int ntok, int lpr_hint, const NormTail* tail, bool* tail_fused) {
     if (tail_fused) *tail_fused = false;
     const int nsseg = ((w.K >> 8) + 7) / 8;
+    if (w.rg_type && ntok >= 16 && !lpr_hint && kq_mfma()) { // K-quant rows on the matrix cores (k_gemm_kq_mfma)
+        const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
+        const int rgs = (nrows + 31) / 32;
+        Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
+                                           out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr));
+        return;
+    }
     if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
         int lpr = lpr_hint;
         if (!lpr) lpr = ((long)(nrows / 32) * nsseg >= 512) ? 2 : ((long)(nrows / 16) * nsseg >= 256) ? 4 : 8;
@@ -292,8 +304,15 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
 
 // gate/up GEMM + SwiGLU + int8 quantisation for batched steps (ntok >= 16, pure Q8_0, K = 1024 or 2048)
 bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok) {
-    if (wgu.rg_type || ntok < 16 || (wgu.K != 1024 && wgu.K != 2048) || (ff & 31)) return false;
+    if (ntok < 16 || (wgu.K != 1024 && wgu.K != 2048) || (ff & 31)) return false;
     const int rgs = ff / 32, ntiles = (ntok + 31) / 32;
+    if (wgu.rg_type) { // K-quant gate / up rows (one type for both, see Transformer): the matrix-core form with the SwiGLU + quant epilogue
+        if (!kq_mfma() || wgu.nparts != 1) return false;
+        int z = mfma_ztiles(rgs, 1, ntok);
+        if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
+        Q3_TS_SWITCH(wgu, hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad));
+        return true;
+    }
     if (!gemm_v1(ntok) && (long)rgs * ntiles >= wave_form_min()) {
         hipLaunchKernelGGL((k_gemm_q8_wave<true>), dim3((rgs + 3) / 4, 1, ntiles), dim3(256), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
         return true;
@@ -523,6 +542,137 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
         }
     }
     if (!GU) norm_tail(tail, ntok, reinterpret_cast<unsigned char*>(&red[0][0][0])); // the consumer's residual + RMSNorm + quant (norm_tail.h)
+}
+
+// -----------------------------------------------------------------------------------------------------
+// K-quant form of the matrix-core GEMM (Q5_K_M files, >= 16 tokens): the packed Q5_K / Q6_K planes are unpacked into the same int8 B operand
+// the Q8_0 kernel loads ready-made (WSlice<2, WT>: lane = half * 32 + row, 16 weights of the block), and v_mfma_i32_32x32x32_i8 again delivers the
+// exact integer block dots of 32 tokens x 32 rows.  What differs is the chain that follows (spec S3, K-quant rows):
+//   Q5_K  acc = fma(d * f(sc_b * idot) - dmin * f(m_b * xsum), dx, acc)     xsum[token] = sum of the activation block -- a second MFMA against an
+//                                                                          all-ones B tile puts it in every column of the C layout
+//   Q6_K  acc = fma(d * f(s_lo * idot_lo + s_hi * idot_hi), dx, acc)         the two 16-element halves are separate sub-blocks: two MFMAs with the
+//         other half's lanes of B zeroed; stored values are q + 32, so idot_x = (stored dot) - 32 * xsum_x (two more MFMAs against half-ones tiles)
+// d, dmin, sc_b, m_b belong to the lane's weight row (C column); dx[token, block] comes, as in the Q8_0 kernel, from the f32 matrix pipe: an outer
+// product with 1.0 lays the activation scales of two blocks out in the C layout.  Built for 2 waves per SIMD (the extra accumulators do not fit 128 VGPRs).
+// Before this kernel the batched path of a Q5_K_M file swept the weights once per 8 tokens (k_gemv_kq z tiles): C3 247 audio-s/s against 620 on Q8_0.
+// -----------------------------------------------------------------------------------------------------
+template <bool GU, int TS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
+               int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+    __shared__ float red[8][32][33];
+    __shared__ float gate_s[GU ? 4 : 1][GU ? 1024 : 1];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    int nsg = nseg - sseg * 8;
+    if (nsg > 8) nsg = 8;
+    const bool active = seg < nseg;
+    const int ntiles = (ntok + 31) >> 5;
+    constexpr int NM = GU ? 2 : 1;
+    const int row_first = row0 + blockIdx.x * 32; // (a workgroup's rows sit in one 32-row group: one weight type)
+    wslice_dispatch<TS>(w, (row_first > w.Npad - 1 ? w.Npad - 1 : row_first) >> 5, [&](auto tag) {
+        constexpr int WT = decltype(tag)::value;
+        constexpr bool Q5 = WT == Q3_T_Q5_K, Q6 = WT == Q3_T_Q6_K;
+#pragma unroll 1
+        for (int q = 0; q < NM; q++) {
+            WSlice<2, WT> ws;
+            ws.dwv = make_uint4(0, 0, 0, 0); ws.mv = make_uint4(0, 0, 0, 0);
+            int row = row_first + r + q * ff;
+            if (row > w.Npad - 1) row = w.Npad - 1;
+            if (active) { ws.load(w, row >> 5, row & 31, seg, half, 0); ws.finish(half); }
+            const float d0 = h2f(half_of(ws.dwv, 0)), d1 = h2f(half_of(ws.dwv, 1));
+            int lt = 0;
+#pragma unroll 1
+            for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z, lt++) {
+                const int tok0 = tt * 32;
+                if (active) {
+                    int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
+                    if (atok > ntok - 1) atok = ntok - 1;
+                    const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+                    const uint4 dxa = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8); // this token's 8 block scales
+                    float acc[16];
+#pragma unroll
+                    for (int g = 0; g < 16; g++) acc[g] = 0.0f;
+                    const i32x4v ones = i32x4v{0x01010101, 0x01010101, 0x01010101, 0x01010101}, zero4 = i32x4v{0, 0, 0, 0};
+#pragma unroll
+                    for (int ip = 0; ip < 4; ip++) { // block pairs: one f32 MFMA lays out the activation scales of blocks 2 ip (lanes 0..31) and 2 ip + 1
+                        f32x32q D;
+#pragma unroll
+                        for (int g = 0; g < 32; g++) D[g] = 0.0f;
+                        const uint32_t ex = half ? half_of(dxa, 2 * ip + 1) : half_of(dxa, 2 * ip);
+                        D = __builtin_amdgcn_mfma_f32_32x32x1f32(h2f(ex), 1.0f, D, 0, 0, 0);
+#pragma unroll
+                        for (int i2 = 0; i2 < 2; i2++) {
+                            const int i = 2 * ip + i2;
+                            const i32x4v av = *reinterpret_cast<const i32x4v*>(xp + i * 32);
+                            const i32x4v wv = i32x4v{(int)ws.wv[i].x, (int)ws.wv[i].y, (int)ws.wv[i].z, (int)ws.wv[i].w};
+                            i32x16 z16;
+#pragma unroll
+                            for (int g = 0; g < 16; g++) z16[g] = 0;
+                            if (Q5) {
+                                const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wv, z16, 0, 0, 0);
+                                const i32x16 cx = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, ones, z16, 0, 0, 0);
+                                const int scb = ws.mbyte(i), mb = ws.mbyte(8 + i);
+#pragma unroll
+                                for (int g = 0; g < 16; g++) {
+                                    const int i1 = scb * c[g], i2v = mb * cx[g];
+                                    const float a = d0 * (float)i1;
+                                    const float a2 = d1 * (float)i2v;
+                                    const float diff = a - a2;
+                                    acc[g] = q3_fmaf(diff, D[16 * i2 + g], acc[g]);
+                                }
+                            } else if (Q6) {
+                                const i32x4v wlo = half ? zero4 : wv, whi = half ? wv : zero4, olo = half ? zero4 : ones, ohi = half ? ones : zero4;
+                                const i32x16 clo = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wlo, z16, 0, 0, 0);
+                                const i32x16 chi = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, whi, z16, 0, 0, 0);
+                                const i32x16 xlo = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, olo, z16, 0, 0, 0);
+                                const i32x16 xhi = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, ohi, z16, 0, 0, 0);
+                                const int s0 = (int)(int8_t)ws.mbyte(2 * i), s1 = (int)(int8_t)ws.mbyte(2 * i + 1);
+#pragma unroll
+                                for (int g = 0; g < 16; g++) {
+                                    const int isum = (clo[g] - 32 * xlo[g]) * s0 + (chi[g] - 32 * xhi[g]) * s1;
+                                    const float a = d0 * (float)isum;
+                                    acc[g] = q3_fmaf(a, D[16 * i2 + g], acc[g]);
+                                }
+                            } else { // Q8_0 row group of a K-quant matrix: f(idot) * (dw * dx)
+                                const i32x16 c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av, wv, z16, 0, 0, 0);
+                                const float dwf = h2f(half_of(ws.dwv, i));
+#pragma unroll
+                                for (int g = 0; g < 16; g++) acc[g] = q3_fmaf((float)c[g], dwf * D[16 * i2 + g], acc[g]);
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
+                }
+                __syncthreads();
+                for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
+                    const int m = t >> 5, rr = t & 31, tok = tok0 + m;
+                    float S = red[0][m][rr];
+                    for (int s2 = 1; s2 < nsg; s2++) S = S + red[s2][m][rr];
+                    if (!GU) {
+                        const int orow = blockIdx.x * 32 + rr;
+                        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+                    } else if (q == 0) gate_s[lt][t] = S; // read back by the same thread in pass 1
+                    else {
+                        const float y = q3_swiglu(gate_s[lt][t], S);
+                        float amax = q3_fabsf(y);
+                        amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+                        amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
+                        const float dd = amax / 127.0f;
+                        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+                        if (tok < ntok) {
+                            aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
+                            if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+                        }
+                    }
+                }
+                __syncthreads(); // red is rewritten by the next tile
+            }
+        }
+    });
 }
 
 // -----------------------------------------------------------------------------------------------------

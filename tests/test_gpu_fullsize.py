@@ -104,23 +104,27 @@ def full_model_q5(synth_tool, full_model):
 def test_fullsize_q5_k_m_packed_planes_vs_oracle(gpu, oracle, full_model_q5, vivian):
     """Q5_K_M at the real dimensions (BASELINE configs[0] quantisation): the K-quant rows stay packed in HBM (nibble + bit planes) and every
     kernel body that unpacks them -- fused B = 1 path (k_gemv_q8_norm / k_gateup_swiglu / k_gemv_kq for Q5_K, Q6_K and the mixed q,k,v
-    matrix) at K = 2048 / 6144 (talker) and 1024 / 3072 (predictor, two super-segments), then a 12-slot batch through the z-tiled GEMV --
+    matrix) at K = 2048 / 6144 (talker) and 1024 / 3072 (predictor, two super-segments), then a 20-slot batch through the matrix-core K-quant GEMM and a 12-slot batch through the z-tiled GEMV --
     must reproduce the oracle's Q5_K / Q6_K block arithmetic bit for bit."""
-    ge = gpu.Engine(full_model_q5, "q5_k_m", max_batch=12, max_steps=16, load_codec=False)
+    ge = gpu.Engine(full_model_q5, "q5_k_m", max_batch=20, max_steps=16, load_codec=False)
     b5 = ge.bytes_per_step(1, 16)
     prompts = []
-    for i in range(12):
+    for i in range(20):
         rng = np.random.default_rng(900 + i)
         prompts.append(ge.assets.build_core(rng.integers(0, 4000, 3 + (i % 2)).astype(np.int32), lang_id=2055, spk_emb=vivian))
     single = ge.generate_batch([prompts[0]], max_steps=4, mask_eos=True)[0]["codes"]
     oe = oracle.Engine(os.path.join(full_model_q5, "gguf_q5_k_m"), None, 8)
     oc, _ = oe.generate(prompts[0], max_steps=4, mask_eos=True)
     assert np.array_equal(oc, single)
-    res = ge.generate_batch(prompts, max_steps=3, mask_eos=True)
+    res = ge.generate_batch(prompts, max_steps=3, mask_eos=True)   # 20 slots: the K-quant matrix-core GEMM (k_gemm_kq_mfma) at K = 1024 ... 6144
     assert np.array_equal(res[0]["codes"], single[:3])
-    oc5, _ = oe.generate(prompts[5], max_steps=3, mask_eos=True)
+    for i in (5, 17):
+        oci, _ = oe.generate(prompts[i], max_steps=3, mask_eos=True)
+        assert np.array_equal(oci, res[i]["codes"]), i
     oe.close()
-    assert np.array_equal(oc5, res[5]["codes"])
+    res12 = ge.generate_batch(prompts[:12], max_steps=3, mask_eos=True)   # 12 slots: the z-tiled GEMV form of the same arithmetic
+    for i in range(12):
+        assert np.array_equal(res12[i]["codes"], res[i]["codes"]), i
     ge.close()
     # packed planes: 0.75 / 0.875 B per weight with scales and metadata against Q8_0's 1.0625 (int8 planes were 1.19)
     g8 = gpu.Engine(full_model_q5, "q8_0", max_batch=1, max_steps=16, load_codec=False)

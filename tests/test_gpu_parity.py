@@ -539,6 +539,24 @@ def test_q5_k_m_wide_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
     ge.close(); oe.close()
 
 
+def test_q5_k_m_matrix_core_batch_matches_oracle(gpu, oracle, tiny_model, vivian):
+    """Q5_K_M with 20 concurrent sequences: from 16 tokens the K-quant rows go through the matrix-core GEMM (k_gemm_kq_mfma: packed planes unpacked into the int8
+    B operand, Q5_K / Q6_K block chains on the accumulators, the mixed q,k,v matrix by per-workgroup type dispatch, the fused gate/up + SwiGLU form on the
+    talker's K = 2048); the multi-sequence prefill packs > 16 prompt rows as well.  Tokens must equal the oracle's, sequence by sequence."""
+    qdir = os.path.join(tiny_model, "gguf_q5_k_m")
+    ge = gpu.Engine(tiny_model, "q5_k_m", max_batch=20, max_steps=8, load_codec=False)
+    oe = oracle.Engine(qdir, None, 4)
+    rng = np.random.default_rng(72)
+    prompts = [ge.assets.build_core(rng.integers(0, 4000, 2 + i).astype(np.int32), lang_id=2055, spk_emb=vivian) for i in range(20)]
+    res = ge.generate_batch(prompts, max_steps=[3 + i % 3 for i in range(20)], mask_eos=True)
+    st = ge.stats()
+    assert st["slot_frames"] / max(st["graph_frames"], 1) >= 16, "the >= 16-token graph widths were not exercised"
+    for i in (0, 3, 7, 12, 19):
+        oc, _ = oe.generate(prompts[i], max_steps=3 + i % 3, mask_eos=True)
+        assert np.array_equal(oc, res[i]["codes"]), i
+    ge.close(); oe.close()
+
+
 def test_bf16_engine_matches_oracle(gpu, oracle, tiny_model, vivian):
     """BASELINE.json configs[4] weight type (bf16): f32 activations, float-weight GEMV (spec S3 float form), bit-exact tokens."""
     qdir = os.path.join(tiny_model, "gguf_bf16")
