@@ -140,9 +140,10 @@ void init_kernel_attributes() {
     init_fused_kernel_attributes();
     done[dev] = true;
 }
+static bool kq_wpe4() { static const bool on = [] { const char* e = std::getenv("Q3_KQ_MFMA_WPE4"); return e ? e[0] == '1' : false; }(); return on; } // measured: the 128-VGPR build of the Q5_K body (36-112 B of scratch, two workgroups per CU) is SLOWER: C3 on Q5_K_M 455 vs 487 audio-s/s
 static bool kq_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_KQ_MFMA"); return e ? e[0] == '1' : true; }(); return on; } // 0: K-quant batches through the z-tiled GEMV
-template <bool GU, int TS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <bool GU, int TS, int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
 static bool q8_scale_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? e[0] == '1' : true; }(); return on; }
@@ -243,8 +244,10 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (w.rg_type && ntok >= 16 && !lpr_hint && kq_mfma()) { // K-quant rows on the matrix cores (k_gemm_kq_mfma)
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
-        Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                                           out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr));
+        // (opt-in Q3_KQ_MFMA_WPE4=1: the Q5_K / Q8_0 bodies squeezed into 128 VGPRs for two workgroups per CU -- measured slower, see kq_wpe4)
+        Q3_TS_SWITCH(w, { if (kq_wpe4() && (TS == Q3_T_Q5_K || TS == Q3_T_Q8_0))
+                              hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS, 4>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+                          else hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS, 2>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr); });
         return;
     }
     if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
@@ -310,7 +313,8 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
         if (!kq_mfma() || wgu.nparts != 1) return false;
         int z = mfma_ztiles(rgs, 1, ntok);
         if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-        Q3_TS_SWITCH(wgu, hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad));
+        Q3_TS_SWITCH(wgu, { if (kq_wpe4() && (TS == Q3_T_Q5_K || TS == Q3_T_Q8_0)) hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS, 4>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+                            else hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS, 2>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad); });
         return true;
     }
     if (!gemm_v1(ntok) && (long)rgs * ntiles >= wave_form_min()) {
@@ -556,8 +560,8 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 // product with 1.0 lays the activation scales of two blocks out in the C layout.  Built for 2 waves per SIMD (the extra accumulators do not fit 128 VGPRs).
 // Before this kernel the batched path of a Q5_K_M file swept the weights once per 8 tokens (k_gemv_kq z tiles): C3 247 audio-s/s against 620 on Q8_0.
 // -----------------------------------------------------------------------------------------------------
-template <bool GU, int TS>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
+template <bool GU, int TS, int WPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ float red[8][32][33];
@@ -617,7 +621,7 @@ k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
                                 const int scb = ws.mbyte(i), mb = ws.mbyte(8 + i);
 #pragma unroll
                                 for (int g = 0; g < 16; g++) {
-                                    const int i1 = scb * c[g], i2v = mb * cx[g];
+                                    const int i1 = __mul24(scb, c[g]), i2v = __mul24(mb, cx[g]); // |idot| <= 32 * 31 * 127 and the 6-bit scales fit v_mul_i32_i24 (full rate; v_mul_lo_u32 is quarter rate)
                                     const float a = d0 * (float)i1;
                                     const float a2 = d1 * (float)i2v;
                                     const float diff = a - a2;
@@ -632,7 +636,7 @@ k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
                                 const int s0 = (int)(int8_t)ws.mbyte(2 * i), s1 = (int)(int8_t)ws.mbyte(2 * i + 1);
 #pragma unroll
                                 for (int g = 0; g < 16; g++) {
-                                    const int isum = (clo[g] - 32 * xlo[g]) * s0 + (chi[g] - 32 * xhi[g]) * s1;
+                                    const int isum = __mul24(clo[g] - 32 * xlo[g], s0) + __mul24(chi[g] - 32 * xhi[g], s1); // 17-bit x 8-bit factors: exact in the 24-bit multiplier
                                     const float a = d0 * (float)isum;
                                     acc[g] = q3_fmaf(a, D[16 * i2 + g], acc[g]);
                                 }

@@ -139,7 +139,7 @@ struct WSlice {
                 isum += xor_lane<R>(isum); xsum += xor_lane<R>(xsum);
                 // the block's term is finished in the lane pair that holds the block (all of its inputs are there); only the result travels
                 const int bl = i * BPL + bil;
-                const int i1 = mbyte(bl) * isum, i2 = mbyte(8 + bl) * xsum;
+                const int i1 = __mul24(mbyte(bl), isum), i2 = __mul24(mbyte(8 + bl), xsum); // 6-bit scale x 17-bit dot: exact in v_mul_i32_i24
                 const float a = d0 * (float)i1;
                 const float a2 = d1 * (float)i2;
                 const float diff = a - a2;
@@ -156,7 +156,7 @@ struct WSlice {
             const uint4 xv = *reinterpret_cast<const uint4*>(xseg + (i * BPL + bil) * 32 + half * 16);
             const int bsel = i * BPL + bil; // block of THIS lane's data
             // sum (q - 32) x = sum (stored) x - 32 sum x, exact in int32; the lane's 16 weights are one sub-block
-            int isum = (dot16(wv[i], xv) - 32 * dot16(ones, xv)) * (int)(int8_t)mbyte(2 * bsel + half);
+            int isum = __mul24(dot16(wv[i], xv) - 32 * dot16(ones, xv), (int)(int8_t)mbyte(2 * bsel + half));
             isum += xor_lane<R>(isum);
             const float a = d0 * (float)isum;
 #pragma unroll
