@@ -15,6 +15,7 @@ timeout -k 10 300 python bench.py --no-cpu-baseline --no-c2-leg --batch 256 --re
 timeout -k 10 300 python bench.py --no-cpu-baseline --no-c2-leg --requests 192 --ragged > $OUT/bench_c3_ragged192.json 2> $OUT/e.err && line $OUT/bench_c3_ragged192.json || tail -3 $OUT/e.err
 timeout -k 10 300 python bench.py --config c5 --no-cpu-baseline > $OUT/bench_c5.json 2> $OUT/e.err && line $OUT/bench_c5.json || tail -3 $OUT/e.err
 timeout -k 10 300 python bench.py --config c2 --no-cpu-baseline > $OUT/bench_c2.json 2> $OUT/e.err && line $OUT/bench_c2.json || tail -3 $OUT/e.err
+timeout -k 10 300 python bench.py --quant q5_k_m --no-cpu-baseline --no-c2-leg > $OUT/bench_c3_q5_k_m.json 2> $OUT/e.err && line $OUT/bench_c3_q5_k_m.json || tail -3 $OUT/e.err
 timeout -k 10 300 python bench.py --config c2 --quant q5_k_m --no-cpu-baseline > $OUT/bench_c2_q5_k_m.json 2> $OUT/e.err && line $OUT/bench_c2_q5_k_m.json || tail -3 $OUT/e.err
 timeout -k 10 300 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-c2-leg > $OUT/bench_torchrun1.json 2> $OUT/e.err && line $OUT/bench_torchrun1.json || tail -3 $OUT/e.err
 Q3_BENCH_FORCE_DIST=1 MASTER_ADDR=127.0.0.1 MASTER_PORT=29519 RANK=0 WORLD_SIZE=1 LOCAL_RANK=0 timeout -k 10 300 python bench.py --gpus 1 --steps 8 --warmup 2 --no-cpu-baseline --no-c2-leg > $OUT/bench_rccl1.json 2> $OUT/e.err && line $OUT/bench_rccl1.json || tail -3 $OUT/e.err
