@@ -956,6 +956,12 @@ __global__ void k_hist_all(HistTable tab, const int64_t* __restrict__ meta, int 
     if (save) h[i] = w[(size_t)e.T * e.C + i]; // the last H rows of (history + new rows) become the next call's history
     else w[i] = h[i];
 }
+// a stream's histories back to zero (new utterance): one launch for every convolution instead of one memset node per history (37 per request)
+__global__ void k_hist_zero(HistTable tab, int stream) {
+    const HistDesc e = tab.d[blockIdx.z];
+    const size_t n = (size_t)e.H * e.C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) e.hist[(size_t)stream * n + i] = 0.0f;
+}
 // final conv (cout = 1): one wave per output sample, lanes split the 7*C products (coalesced rows), butterfly sum, clamp
 __global__ void __launch_bounds__(256) k_conv_out_wave(const float* __restrict__ in_ext, int C, const float* __restrict__ w, float bias,
                                                        float* __restrict__ pcm, int n, RowMap im) {
@@ -1325,7 +1331,20 @@ void CodecDecoder::state_import(int s, const float* in) {
 void CodecDecoder::reset_async(hipStream_t st, int s) {
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
-    for (Ext* e : m.all_ext) if (e->H) Q3_HIP(hipMemsetAsync(e->hist.p + (size_t)s * e->H * e->C, 0, (size_t)e->H * e->C * 4, st));
+    HistTable tab{};
+    size_t mx = 0;
+    auto flush = [&]() {
+        if (tab.n) hipLaunchKernelGGL(k_hist_zero, dim3((unsigned)((mx + 255) / 256), 1, tab.n), dim3(256), 0, st, tab, s);
+        tab.n = 0; mx = 0;
+    };
+    for (Ext* e : m.all_ext) {
+        if (!e->H) continue;
+        HistDesc d{}; d.hist = e->hist.p; d.H = e->H; d.C = e->C;
+        tab.d[tab.n++] = d;
+        mx = std::max(mx, (size_t)e->H * e->C);
+        if (tab.n == 48) flush();
+    }
+    flush();
     m.kv_len[s] = 0; m.n_seen[s] = 0;
 }
 
