@@ -88,3 +88,13 @@ def test_reader_reports_missing_contract_and_rejects_garbage(q3, tiny_model, tmp
         open(p, "wb").write(data)
         with pytest.raises(q3.Q3Error):
             q3.OnnxModel(p)
+
+
+def test_executor_operator_table(q3):
+    """the executor's operator table is a host-side lookup (no device needed): what an exported encoder / decoder may use, and what it may not"""
+    Q = q3
+    for op in ("Conv", "ConvTranspose", "MatMul", "Gemm", "LayerNormalization", "Softmax", "Gather", "Slice", "Concat", "Reshape", "Shape", "Where", "ArgMin", "Pad", "Elu", "Erf",
+               "CumSum", "Range", "ConstantOfShape", "Expand", "Tile", "ReduceMean", "InstanceNormalization", "BatchNormalization", "Split", "Cast", "Clip", "Pow"):
+        assert Q.onnx_op_executable(op), op
+    for op in ("LSTM", "GRU", "Resize", "Einsum", "ScatterND", "TopK", "NonZero", "NotAnOp"):
+        assert not Q.onnx_op_executable(op), op
