@@ -238,6 +238,7 @@ void q3tts_tokenizer_close(q3tts_tokenizer* t);
 int32_t q3tts_tokenizer_encode(q3tts_tokenizer* t, const char* text_utf8, int32_t* ids, int32_t cap); /* count (may exceed cap), < 0 error */
 int64_t q3tts_tokenizer_decode(q3tts_tokenizer* t, const int32_t* ids, int32_t n, char* buf, int64_t cap); /* byte length, < 0 error */
 int32_t q3tts_tokenizer_vocab_size(q3tts_tokenizer* t);
+int64_t q3tts_text_nfc(const char* utf8, char* out, int64_t cap); /* NFC as the tokenizer's normaliser applies it; returns the size needed (with NUL) */
 
 /* ---- ONNX graph ingestion (host code, no GPU needed) ----
  * A minimal reader of ONNX ModelProto files (protobuf wire format walked by hand): what `ort::Session` parses for the reference's

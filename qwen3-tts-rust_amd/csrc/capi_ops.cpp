@@ -280,6 +280,14 @@ int64_t q3tts_tokenizer_decode(q3tts_tokenizer* t, const int32_t* ids, int32_t n
     return (int64_t)t->text.size();
     Q3_API_END(-1)
 }
+int64_t q3tts_text_nfc(const char* utf8, char* out, int64_t cap) {
+    try {
+        if (!utf8) return 0;
+        const std::string r = q3::nfc_utf8(utf8);
+        if (out && cap > 0) { const size_t n = std::min<size_t>((size_t)cap - 1, r.size()); memcpy(out, r.data(), n); out[n] = 0; }
+        return (int64_t)r.size() + 1;
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return -1; }
+}
 int32_t q3tts_tokenizer_vocab_size(q3tts_tokenizer* t) { return t ? t->t->vocab_size() : 0; }
 } // extern "C"
 

@@ -6,7 +6,7 @@
 // pre-tokeniser with the pattern below (behaviour "isolated") followed by ByteLevel (no prefix space, no regex); a BPE model over the
 // byte-level alphabet (vocab + ranked merges); ByteLevel decoder.  Parity is PINNED: tests/test_tokenizer_cpu.py builds tokenizer.json
 // files with the Python `tokenizers` package (0.22.2, the crate's version) and compares ids string by string.
-// Not implemented (rejected at load or documented): normalisers other than NFC / none (NFC itself is assumed of the input, not applied),
+// Not implemented (rejected at load or documented): normalisers other than NFC / none,
 // added tokens with lstrip / rstrip / single_word, byte_fallback, dropout, unk_token.
 #include "tokenizer.h"
 #include "q3_common.h"
@@ -143,6 +143,81 @@ std::vector<Cp> decode_utf8(const std::string& t) {
     return out;
 }
 
+// ---- NFC (the Qwen tokenizer's normaliser; UAX #15) over the generated tables of unicode_tables.h ----
+static uint32_t nfc_ccc(uint32_t cp) {
+    if (cp < 0x300) return 0;
+    size_t lo = 0, hi = sizeof(kNfcCcc) / sizeof(kNfcCcc[0]);
+    while (lo < hi) { const size_t mid = (lo + hi) / 2; if (kNfcCcc[mid][1] < cp) lo = mid + 1; else hi = mid; }
+    return (lo < sizeof(kNfcCcc) / sizeof(kNfcCcc[0]) && kNfcCcc[lo][0] <= cp) ? kNfcCcc[lo][2] : 0;
+}
+static void nfc_decompose(uint32_t cp, std::vector<uint32_t>& out) {
+    if (cp >= 0xAC00 && cp <= 0xD7A3) { // Hangul syllable -> L V (T)
+        const uint32_t s = cp - 0xAC00, t = s % 28;
+        out.push_back(0x1100 + s / 588); out.push_back(0x1161 + (s % 588) / 28);
+        if (t) out.push_back(0x11A7 + t);
+        return;
+    }
+    if (cp >= 0xC0) {
+        size_t lo = 0, hi = sizeof(kNfcDecompIdx) / sizeof(kNfcDecompIdx[0]);
+        while (lo < hi) { const size_t mid = (lo + hi) / 2; if (kNfcDecompIdx[mid][0] < cp) lo = mid + 1; else hi = mid; }
+        if (lo < sizeof(kNfcDecompIdx) / sizeof(kNfcDecompIdx[0]) && kNfcDecompIdx[lo][0] == cp) {
+            for (uint32_t k = 0; k < kNfcDecompIdx[lo][2]; k++) out.push_back(kNfcDecompData[kNfcDecompIdx[lo][1] + k]);
+            return;
+        }
+    }
+    out.push_back(cp);
+}
+static uint32_t nfc_compose(uint32_t a, uint32_t b) { // 0 = no primary composite
+    if (a >= 0x1100 && a <= 0x1112 && b >= 0x1161 && b <= 0x1175) return 0xAC00 + ((a - 0x1100) * 21 + (b - 0x1161)) * 28;
+    if (a >= 0xAC00 && a <= 0xD7A3 && (a - 0xAC00) % 28 == 0 && b >= 0x11A8 && b <= 0x11C2) return a + (b - 0x11A7);
+    size_t lo = 0, hi = sizeof(kNfcComp) / sizeof(kNfcComp[0]);
+    while (lo < hi) {
+        const size_t mid = (lo + hi) / 2;
+        if (kNfcComp[mid][0] < a || (kNfcComp[mid][0] == a && kNfcComp[mid][1] < b)) lo = mid + 1; else hi = mid;
+    }
+    return (lo < sizeof(kNfcComp) / sizeof(kNfcComp[0]) && kNfcComp[lo][0] == a && kNfcComp[lo][1] == b) ? kNfcComp[lo][2] : 0;
+}
+std::string nfc_utf8_impl(const std::string& text) {
+    bool ascii = true;
+    for (unsigned char c : text) if (c >= 0x80) { ascii = false; break; }
+    if (ascii) return text; // ASCII is its own NFC
+    const std::vector<Cp> cps = decode_utf8(text);
+    std::vector<uint32_t> d;
+    d.reserve(cps.size() + 8);
+    for (size_t i = 0; i + 1 < cps.size(); i++) nfc_decompose(cps[i].cp, d);
+    // canonical ordering: stable sort of every run of non-starters by combining class
+    for (size_t i = 0; i < d.size();) {
+        if (nfc_ccc(d[i]) == 0) { i++; continue; }
+        size_t e = i;
+        while (e < d.size() && nfc_ccc(d[e]) != 0) e++;
+        std::stable_sort(d.begin() + (long)i, d.begin() + (long)e, [](uint32_t x, uint32_t y) { return nfc_ccc(x) < nfc_ccc(y); });
+        i = e;
+    }
+    // canonical composition (UAX #15 reference form)
+    if (!d.empty()) {
+        size_t starter_pos = 0, comp_pos = 1;
+        uint32_t starter_ch = d[0];
+        int last_class = (int)nfc_ccc(starter_ch);
+        if (last_class != 0) last_class = 256; // a string that starts with a combining mark: nothing composes onto it
+        for (size_t pos = 1; pos < d.size(); pos++) {
+            const uint32_t ch = d[pos];
+            const int ch_class = (int)nfc_ccc(ch);
+            const uint32_t composite = nfc_compose(starter_ch, ch);
+            if (composite && (last_class < ch_class || last_class == 0)) { d[starter_pos] = composite; starter_ch = composite; }
+            else {
+                if (ch_class == 0) { starter_pos = comp_pos; starter_ch = ch; }
+                last_class = ch_class;
+                d[comp_pos++] = ch;
+            }
+        }
+        d.resize(comp_pos);
+    }
+    std::string out;
+    out.reserve(text.size());
+    for (uint32_t cp : d) JParser::utf8(out, cp);
+    return out;
+}
+
 // The Qwen2 / GPT-4-style pre-tokenisation pattern, matched the way a backtracking leftmost-first engine does (alternatives in order):
 //   (?i:'s|'t|'re|'ve|'m|'ll|'d) | [^\r\n\p{L}\p{N}]?\p{L}+ | \p{N} | ?[^\s\p{L}\p{N}]+[\r\n]* | \s*[\r\n]+ | \s+(?!\S) | \s+
 const char* kQwenPattern = "(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\\r\\n\\p{L}\\p{N}]?\\p{L}+|\\p{N}| ?[^\\s\\p{L}\\p{N}]+[\\r\\n]*|\\s*[\\r\\n]+|\\s+(?!\\S)|\\s+";
@@ -209,7 +284,7 @@ struct Tokenizer::Impl {
     std::map<std::pair<int32_t, int32_t>, std::pair<int32_t, int32_t>> merges; // (left id, right id) -> (rank, merged id)
     std::vector<std::pair<std::string, int32_t>> added;                        // content, id (matched leftmost-longest on the raw text)
     std::map<int32_t, std::string> added_by_id;
-    bool ignore_merges = false; bool qwen_split = false; bool byte_level = true;
+    bool ignore_merges = false; bool qwen_split = false; bool byte_level = true; bool nfc = false;
     std::map<std::string, std::vector<int32_t>> cache;
 
     void bpe(const std::string& piece, std::vector<int32_t>& out) { // piece: byte-level string (UTF-8 of the mapped alphabet)
@@ -253,8 +328,9 @@ struct Tokenizer::Impl {
         if (cache.size() < 100000) cache[piece] = ids;
         out.insert(out.end(), ids.begin(), ids.end());
     }
-    void encode_section(const std::string& text, std::vector<int32_t>& out) {
-        if (text.empty()) return;
+    void encode_section(const std::string& raw, std::vector<int32_t>& out) {
+        if (raw.empty()) return;
+        const std::string text = nfc ? nfc_utf8_impl(raw) : raw; // the normaliser runs on the text between added tokens, before the pre-tokeniser
         const std::vector<Cp> cps = decode_utf8(text);
         const size_t n = cps.size() - 1;
         const ByteMap& bm = bytemap();
@@ -313,7 +389,10 @@ Tokenizer::Tokenizer(const std::string& path) : impl_(new Impl()) {
         m.added_by_id[(int32_t)idv->num] = content;
     }
     std::sort(m.added.begin(), m.added.end(), [](const std::pair<std::string, int32_t>& a, const std::pair<std::string, int32_t>& b) { return a.first.size() > b.first.size(); });
-    if (const JVal* nz = root.get("normalizer")) if (nz->kind == JVal::Obj && nz->s("type") != "NFC") throw Error("Failed to load tokenizer: normalizer " + nz->s("type") + " is not supported (NFC or none)");
+    if (const JVal* nz = root.get("normalizer")) if (nz->kind == JVal::Obj) {
+        if (nz->s("type") != "NFC") throw Error("Failed to load tokenizer: normalizer " + nz->s("type") + " is not supported (NFC or none)");
+        m.nfc = true;
+    }
     // pre-tokeniser: ByteLevel alone (GPT-2 family with its own regex: not supported), or Sequence[Split(pattern, isolated), ByteLevel(use_regex = false)]
     m.byte_level = false;
     std::function<void(const JVal&)> scan = [&](const JVal& p) {
@@ -370,6 +449,7 @@ std::string Tokenizer::decode(const std::vector<int32_t>& ids) const { // decode
     flush();
     return out;
 }
+std::string nfc_utf8(const std::string& text) { return nfc_utf8_impl(text); }
 int32_t Tokenizer::vocab_size() const { return (int32_t)std::max(impl_->id_to_tok.size(), impl_->added_by_id.empty() ? (size_t)0 : (size_t)impl_->added_by_id.rbegin()->first + 1); }
 
 } // namespace q3

@@ -21,4 +21,7 @@ private:
     std::unique_ptr<Impl> impl_;
 };
 
+// NFC of a UTF-8 string (UAX #15; tables of unicode_tables.h): what the tokenizer's normaliser applies between added tokens
+std::string nfc_utf8(const std::string& text);
+
 } // namespace q3

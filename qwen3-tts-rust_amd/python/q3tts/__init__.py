@@ -72,7 +72,7 @@ SYMBOLS = [
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
     "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
     "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
-    "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
+    "q3tts_text_nfc", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
@@ -650,6 +650,18 @@ class OnnxDecoder:
         n = C.c_int64()
         _chk(lib().q3tts_onnx_decoder_decode(self.h, codes.ctypes.data, codes.shape[0], 1 if is_final else 0, out.ctypes.data, out.size, C.byref(n)))
         return out[: n.value].copy()
+
+
+def text_nfc(text):
+    """NFC as the tokenizer's normaliser applies it (q3tts_text_nfc)"""
+    L = lib()
+    L.q3tts_text_nfc.restype = C.c_int64
+    L.q3tts_text_nfc.argtypes = [C.c_char_p, C.c_char_p, C.c_int64]
+    raw = text.encode("utf-8", "surrogatepass")
+    n = L.q3tts_text_nfc(raw, None, 0)
+    buf = C.create_string_buffer(int(n))
+    L.q3tts_text_nfc(raw, buf, n)
+    return buf.raw[: n - 1].decode("utf-8", "surrogatepass")
 
 
 def onnx_op_executable(op_type):

@@ -59,11 +59,21 @@ def test_encode_decode_match_tokenizers_package(q3, tmp_path):
         got = mine.encode(text)
         assert got == ref, (text, got[:20], ref[:20])
         assert mine.decode(ref) == tok.decode(ref, skip_special_tokens=False), text
-    # documented limitation: the NFC normaliser is ASSUMED of the input, not applied -- text that is already NFC (what keyboards and the
-    # reference's CLI strings produce) is exact; a decomposed sequence must be composed by the caller first
+    # the NFC normaliser is applied between added tokens, as the `tokenizers` crate does: decomposed input encodes like its composed form
     import unicodedata
-    dec = "e\u0301 combining"
-    assert mine.encode(unicodedata.normalize("NFC", dec)) == tok.encode(dec, add_special_tokens=False).ids
+    for dec in ("e\u0301 combining", "A\u030a\u0301ngstro\u0308m", "\u1100\u1161\u11a8 \u1112\u1161\u11ab jamo", "q\u0323\u0307 reorder", "\u212b \u2126 singletons",
+                "x<|im_end|>e\u0301<|im_end|>\u0065\u0301", "\u0301 leading mark", "n\u0303o\u0303 \u0915\u093c"):
+        ref = tok.encode(dec, add_special_tokens=False).ids
+        assert mine.encode(dec) == ref, dec
+        assert mine.encode(unicodedata.normalize("NFC", dec)) == ref, dec
+    pool = [chr(c) for c in list(range(0x20, 0x7F)) + list(range(0xC0, 0x250)) + list(range(0x300, 0x370)) + list(range(0x1100, 0x1113)) + list(range(0x1161, 0x1176)) +
+            list(range(0x11A8, 0x11C3)) + list(range(0xAC00, 0xAC40)) + [0x1E9B, 0x212B, 0x2126, 0x0344, 0x0F73, 0x0958, 0xFB1D, 0x2ADC, 0x4E2D, 0x1F3A4]]
+    for _ in range(3000):  # q3tts_text_nfc against Python's unicodedata (the same Unicode version generated the tables)
+        t = "".join(rng.choice(pool, size=int(rng.integers(1, 12))))
+        assert q3.text_nfc(t) == unicodedata.normalize("NFC", t), [hex(ord(c)) for c in t]
+    for _ in range(200):
+        t = "".join(rng.choice(pool, size=int(rng.integers(1, 16))))
+        assert mine.encode(t) == tok.encode(t, add_special_tokens=False).ids, [hex(ord(c)) for c in t]
     mine.close()
 
 
