@@ -25,7 +25,7 @@ template <typename T> __global__ void k_nd_copy(T* __restrict__ out, const T* __
 }
 
 enum UOp { U_RELU, U_SIGMOID, U_TANH, U_EXP, U_LOG, U_SQRT, U_RECIP, U_NEG, U_ABS, U_SIN, U_COS, U_ERF, U_FLOOR, U_CEIL, U_ROUND, U_SIGN, U_ELU,
-           U_LEAKY, U_HSIG, U_GELU, U_GELU_TANH, U_SOFTPLUS, U_SELU, U_NOT, U_CLIP, U_IDENT, U_SOFTSIGN, U_HSWISH, U_ISNAN };
+           U_LEAKY, U_HSIG, U_GELU, U_GELU_TANH, U_SOFTPLUS, U_SELU, U_NOT, U_CLIP, U_IDENT, U_SOFTSIGN, U_HSWISH, U_ISNAN, U_CELU, U_THRELU, U_MISH, U_TAN, U_ATAN, U_SINH, U_COSH, U_LOG1P_EXP_NEG };
 __device__ __forceinline__ float apply_unary(int op, float x, float a, float b) {
     switch (op) {
         case U_RELU: return x > 0.f ? x : 0.f;
@@ -56,6 +56,13 @@ __device__ __forceinline__ float apply_unary(int op, float x, float a, float b) 
         case U_SOFTSIGN: return x / (1.f + fabsf(x));
         case U_HSWISH: return x * fminf(1.f, fmaxf(0.f, x / 6.f + 0.5f));
         case U_ISNAN: return x != x ? 1.f : 0.f;
+        case U_CELU: return fmaxf(0.f, x) + fminf(0.f, a * (expf(x / a) - 1.f));
+        case U_THRELU: return x > a ? x : 0.f;
+        case U_MISH: return x * tanhf(x > 20.f ? x : log1pf(expf(x)));
+        case U_TAN: return tanf(x);
+        case U_ATAN: return atanf(x);
+        case U_SINH: return sinhf(x);
+        case U_COSH: return coshf(x);
         default: return x;
     }
 }
@@ -340,6 +347,45 @@ __global__ void k_convtr2d(float* __restrict__ out, const float* __restrict__ x,
     }
     out[i] = acc;
 }
+// upper / lower triangle of the last two dims (k = diagonal offset)
+__global__ void k_trilu(float* __restrict__ out, const float* __restrict__ in, int64_t rows, int64_t cols, int64_t k, int upper, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t c = i % cols, r = (i / cols) % rows;
+    const bool keep = upper ? (c - r >= k) : (c - r <= k);
+    out[i] = keep ? in[i] : 0.f;
+}
+// out[outer][j][inner] = data[outer][idx[outer][j][inner]][inner]   (GatherElements along one axis)
+template <typename T> __global__ void k_gather_elems(T* __restrict__ out, const T* __restrict__ data, const int64_t* __restrict__ idx, int64_t nj, int64_t axis_dim, int64_t inner, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t in_ = i % inner, o = i / (inner * nj);
+    int64_t k = idx[i];
+    if (k < 0) k += axis_dim;
+    k = k < 0 ? 0 : k >= axis_dim ? axis_dim - 1 : k;
+    out[i] = data[(o * axis_dim + k) * inner + in_];
+}
+// ScatterND with whole-slice updates: out (a copy of data) [offsets[u] * slice + e] = updates[u * slice + e]
+__global__ void k_scatter_rows(float* __restrict__ out, const float* __restrict__ upd, const int64_t* __restrict__ offsets, int64_t slice, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    out[offsets[i / slice] * slice + i % slice] = upd[i];
+}
+// nearest-neighbour Resize over the trailing spatial dims of an N-d tensor (asymmetric / floor: the exporters' default for integer factors)
+struct ResizeArgs { int rank; int64_t oshape[XR]; int64_t ishape[XR]; float scale[XR]; };
+__global__ void k_resize_nearest(float* __restrict__ out, const float* __restrict__ in, ResizeArgs a, int64_t n) {
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t o = i;
+    int64_t off = 0, stride = 1;
+    for (int d = a.rank - 1; d >= 0; d--) {
+        const int64_t q = i / a.oshape[d], r = i - q * a.oshape[d];
+        int64_t src = (int64_t)floorf((float)r / a.scale[d]);
+        if (src > a.ishape[d] - 1) src = a.ishape[d] - 1;
+        off += src * stride; stride *= a.ishape[d]; i = q;
+    }
+    out[o] = in[off];
+}
 struct PadArgs { int rank; int64_t oshape[XR]; int64_t ishape[XR]; int64_t begin[XR]; int mode; float value; }; // mode 0 constant, 1 reflect, 2 edge
 __global__ void k_pad(float* __restrict__ out, const float* __restrict__ in, PadArgs p, int64_t n) {
     int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
@@ -385,7 +431,8 @@ static const std::map<std::string, int>& unary_table() {
     static const std::map<std::string, int> t = {{"Relu", U_RELU}, {"Sigmoid", U_SIGMOID}, {"Tanh", U_TANH}, {"Exp", U_EXP}, {"Log", U_LOG}, {"Sqrt", U_SQRT},
         {"Reciprocal", U_RECIP}, {"Neg", U_NEG}, {"Abs", U_ABS}, {"Sin", U_SIN}, {"Cos", U_COS}, {"Erf", U_ERF}, {"Floor", U_FLOOR}, {"Ceil", U_CEIL},
         {"Round", U_ROUND}, {"Sign", U_SIGN}, {"Elu", U_ELU}, {"LeakyRelu", U_LEAKY}, {"HardSigmoid", U_HSIG}, {"Gelu", U_GELU}, {"Softplus", U_SOFTPLUS},
-        {"Selu", U_SELU}, {"Not", U_NOT}, {"Softsign", U_SOFTSIGN}, {"HardSwish", U_HSWISH}, {"IsNaN", U_ISNAN}};
+        {"Selu", U_SELU}, {"Not", U_NOT}, {"Softsign", U_SOFTSIGN}, {"HardSwish", U_HSWISH}, {"IsNaN", U_ISNAN}, {"Celu", U_CELU}, {"ThresholdedRelu", U_THRELU},
+        {"Mish", U_MISH}, {"Tan", U_TAN}, {"Atan", U_ATAN}, {"Sinh", U_SINH}, {"Cosh", U_COSH}};
     return t;
 }
 static const std::map<std::string, int>& binary_table() {
@@ -402,7 +449,8 @@ static const std::map<std::string, int>& reduce_table() {
 static const std::set<std::string>& other_ops() {
     static const std::set<std::string> t = {"Identity", "Dropout", "Reshape", "Flatten", "Squeeze", "Unsqueeze", "Transpose", "Concat", "Slice", "Split", "Gather",
         "Shape", "Size", "Constant", "ConstantOfShape", "Range", "Cast", "Expand", "Tile", "Where", "Clip", "Softmax", "LogSoftmax", "LayerNormalization",
-        "InstanceNormalization", "BatchNormalization", "MatMul", "Gemm", "Conv", "ConvTranspose", "Pad", "CumSum", "GlobalAveragePool", "GlobalMaxPool"};
+        "InstanceNormalization", "BatchNormalization", "MatMul", "Gemm", "Conv", "ConvTranspose", "Pad", "CumSum", "GlobalAveragePool", "GlobalMaxPool",
+        "Trilu", "GatherElements", "ScatterND", "Resize", "GroupNormalization", "LpNormalization"};
     return t;
 }
 bool onnx_exec_supports(const std::string& op) { return unary_table().count(op) || binary_table().count(op) || reduce_table().count(op) || other_ops().count(op); }
@@ -675,6 +723,8 @@ void OnnxSession::run() {
                 else if (op == "HardSigmoid") { a = af("alpha", 0.2f); b = af("beta", 0.5f); }
                 else if (op == "Selu") { a = af("alpha", 1.67326319217681884765625f); b = af("gamma", 1.05070102214813232421875f); }
                 else if (op == "Gelu" && as("approximate", "none") == "tanh") u = U_GELU_TANH;
+                else if (op == "Celu") a = af("alpha", 1.0f);
+                else if (op == "ThresholdedRelu") a = af("alpha", 1.0f);
                 out(0, I.unary(u, in(0), a, b));
             } else if (binary_table().count(op)) {
                 int b = binary_table().at(op);
@@ -1156,6 +1206,87 @@ void OnnxSession::run() {
                 const int64_t n = o.numel();
                 if (n) { hipLaunchKernelGGL(k_pad, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), p, n); I.count(); }
                 out(0, o);
+            } else if (op == "Trilu") {
+                const XTensor x = I.as_f32(in(0));
+                Q3_CHECK(x.shape.size() >= 2, "Trilu needs a matrix");
+                const int64_t k2 = has(1) ? I.ints_of(in(1)).at(0) : 0, rows = x.shape[x.shape.size() - 2], cols = x.shape.back(), n = x.numel();
+                XTensor o = I.dev_tensor(in(0).dtype == 9 ? 9 : 1, x.shape);
+                if (n) { hipLaunchKernelGGL(k_trilu, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), rows, cols, k2, (int)ai("upper", 1), n); I.count(); }
+                out(0, in(0).dtype == 7 ? I.as_i64(o) : o);
+            } else if (op == "GatherElements") {
+                const XTensor x = I.to_device(in(0)), idx = I.as_i64(in(1));
+                int64_t a = ai("axis", 0); if (a < 0) a += (int64_t)x.shape.size();
+                Q3_CHECK(idx.shape.size() == x.shape.size(), "GatherElements: rank mismatch");
+                for (size_t d = 0; d < x.shape.size(); d++) Q3_CHECK((int64_t)d == a || idx.shape[d] == x.shape[d], "GatherElements: indices must match the data outside the axis");
+                const int64_t inner = prod(x.shape, (size_t)a + 1), nj = idx.shape[(size_t)a], n = idx.numel();
+                XTensor o = I.dev_tensor(x.dtype, idx.shape);
+                if (n) {
+                    if (x.dtype == 7) hipLaunchKernelGGL(k_gather_elems<int64_t>, grid1(n), dim3(256), 0, 0, I.i64(o), I.i64(x), I.i64(idx), nj, x.shape[(size_t)a], inner, n);
+                    else hipLaunchKernelGGL(k_gather_elems<float>, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), I.i64(idx), nj, x.shape[(size_t)a], inner, n);
+                    I.count();
+                }
+                out(0, o);
+            } else if (op == "ScatterND") {
+                const XTensor x = I.as_f32(in(0)), upd = I.as_f32(in(2));
+                const XTensor ih = I.to_host(in(1)); // index tuples are small (cache positions): evaluated on the host into slice offsets
+                Q3_CHECK(as("reduction", "none") == "none", "ScatterND with a reduction");
+                const int64_t kdim = ih.shape.back(), nup = kdim ? ih.numel() / kdim : 0;
+                Q3_CHECK(kdim >= 1 && kdim <= (int64_t)x.shape.size(), "ScatterND index depth");
+                const int64_t slice = prod(x.shape, (size_t)kdim);
+                const auto st = strides_of(x.shape);
+                std::vector<double> offs((size_t)nup);
+                for (int64_t u = 0; u < nup; u++) {
+                    int64_t off = 0;
+                    for (int64_t d = 0; d < kdim; d++) { int64_t v = (int64_t)ih.hv[(size_t)(u * kdim + d)]; if (v < 0) v += x.shape[(size_t)d]; Q3_CHECK(v >= 0 && v < x.shape[(size_t)d], "ScatterND index out of range"); off += v * st[(size_t)d]; }
+                    offs[(size_t)u] = (double)(off / std::max<int64_t>(slice, 1));
+                }
+                XTensor o = I.dev_tensor(1, x.shape);
+                if (x.numel()) Q3_HIP(hipMemcpyAsync(o.dev->p, x.dev->p, (size_t)x.numel() * 4, hipMemcpyDeviceToDevice, 0));
+                const int64_t n = nup * slice;
+                if (n) {
+                    XTensor od = I.to_device(Impl::host_tensor(7, {nup}, offs));
+                    hipLaunchKernelGGL(k_scatter_rows, grid1(n), dim3(256), 0, 0, I.f(o), I.f(upd), I.i64(od), slice, n);
+                    I.count();
+                }
+                out(0, o);
+            } else if (op == "Resize") {
+                const XTensor x = I.as_f32(in(0));
+                Q3_CHECK(as("mode", "nearest") == "nearest", "Resize: only nearest is implemented");
+                const int rank = (int)x.shape.size();
+                ResizeArgs a{}; a.rank = rank;
+                std::vector<int64_t> os = x.shape;
+                if (has(3)) { os = I.ints_of(in(3)); Q3_CHECK((int)os.size() == rank, "Resize sizes rank"); for (int d = 0; d < rank; d++) a.scale[d] = (float)os[(size_t)d] / (float)x.shape[(size_t)d]; }
+                else { Q3_CHECK(has(2), "Resize needs scales or sizes"); const XTensor sc = I.to_host(in(2)); Q3_CHECK((int)sc.hv.size() == rank, "Resize scales rank");
+                       for (int d = 0; d < rank; d++) { a.scale[d] = (float)sc.hv[(size_t)d]; os[(size_t)d] = (int64_t)std::floor((double)x.shape[(size_t)d] * sc.hv[(size_t)d]); } }
+                for (int d = 0; d < rank; d++) { a.oshape[d] = os[(size_t)d]; a.ishape[d] = x.shape[(size_t)d]; }
+                XTensor o = I.dev_tensor(1, os);
+                const int64_t n = o.numel();
+                if (n) { hipLaunchKernelGGL(k_resize_nearest, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), a, n); I.count(); }
+                out(0, o);
+            } else if (op == "GroupNormalization") {
+                const XTensor x = I.as_f32(in(0)), g = I.as_f32(in(1)), b = I.as_f32(in(2));
+                const int64_t G = ai("num_groups", 1), C = x.shape.at(1), sp = prod(x.shape, 2), rows = x.shape.at(0) * G, cols = (C / G) * sp;
+                Q3_CHECK(G > 0 && C % G == 0, "GroupNormalization groups");
+                XTensor nrm = I.dev_tensor(1, x.shape);
+                if (rows && cols) { hipLaunchKernelGGL(k_norm_rows, dim3((unsigned)rows), dim3(256), 0, 0, I.f(nrm), I.f(x), (const float*)nullptr, (const float*)nullptr, cols, af("epsilon", 1e-5f), 0, (int64_t)1); I.count(); }
+                // per-channel affine (opset 21 form; opset 18 files carry per-group scale / bias of length G)
+                std::vector<int64_t> bs(x.shape.size(), 1); bs[1] = g.numel() == C ? C : G;
+                XTensor y = nrm;
+                if (g.numel() == C) { y = I.binary(B_MUL, nrm, I.reshaped(g, bs), 1); y = I.binary(B_ADD, y, I.reshaped(b, bs), 1); }
+                else { std::vector<int64_t> gs = {x.shape[0], G, C / G}; gs.insert(gs.end(), x.shape.begin() + 2, x.shape.end()); std::vector<int64_t> gb(gs.size(), 1); gb[1] = G;
+                       y = I.binary(B_ADD, I.binary(B_MUL, I.reshaped(nrm, gs), I.reshaped(g, gb), 1), I.reshaped(b, gb), 1); y = I.reshaped(y, x.shape); }
+                out(0, y);
+            } else if (op == "LpNormalization") {
+                const XTensor x = I.as_f32(in(0));
+                int64_t a = ai("axis", -1); if (a < 0) a += (int64_t)x.shape.size();
+                const int64_t p2 = ai("p", 2);
+                Q3_CHECK(p2 == 1 || p2 == 2, "LpNormalization p");
+                int64_t rows, cols;
+                XTensor perm = I.axes_last(x, {a}, rows, cols);
+                std::vector<int64_t> ks = x.shape; ks[(size_t)a] = 1;
+                XTensor nm = I.dev_tensor(1, ks);
+                if (rows) { hipLaunchKernelGGL(k_reduce_rows, dim3((unsigned)rows), dim3(256), 0, 0, I.f(nm), (int64_t*)nullptr, I.f(perm), p2 == 2 ? R_L2 : R_L1, cols, 0); I.count(); }
+                out(0, I.binary(B_DIV, x, nm, 1));
             } else {
                 throw Error("operator is not supported by this executor");
             }

@@ -576,3 +576,42 @@ def test_streaming_decoder_contract_over_the_executor(gpu, tmp_path):
         np.testing.assert_allclose(np.concatenate(got), np.concatenate(exp), rtol=2e-4, atol=2e-5, err_msg=str(chunks))
     assert dec.decode(np.zeros((0, 16), np.int64)).size == 0                         # n_frames == 0 -> empty (onnx.rs:350-353)
     dec.close()
+
+
+def test_more_ops_trilu_scatter_resize_groupnorm(gpu, tmp_path):
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(31)
+    x = rng.standard_normal((2, 6, 5, 7)).astype(np.float32)
+    kv = rng.standard_normal((1, 2, 9, 4)).astype(np.float32)
+    upd = rng.standard_normal((3, 4)).astype(np.float32)
+    gidx = rng.integers(0, 5, (2, 6, 3, 7))
+    gg = rng.standard_normal(6).astype(np.float32); gb = rng.standard_normal(6).astype(np.float32)
+    I = lambda name, v: W.tensor(name, np.asarray(v, np.int64))
+    inits = [I("km1", -1), I("sidx", [[0, 1, 2], [0, 0, 8], [0, 1, 0]]), I("gidx", gidx), W.tensor("upd", upd), W.tensor("gg", gg), W.tensor("gb", gb),
+             W.tensor("scales", np.asarray([1, 1, 2, 3], np.float32)), W.tensor("roi", np.zeros(0, np.float32)), I("sizes", [2, 6, 10, 7])]
+    n = W.node
+    nodes = [n("Trilu", ["x"], ["tu"]), n("Trilu", ["x", "km1"], ["tl"], attrs=[W.attr_int("upper", 0)]),
+             n("GatherElements", ["x", "gidx"], ["ge"], attrs=[W.attr_int("axis", 2)]),
+             n("ScatterND", ["kv", "sidx", "upd"], ["sc"]),
+             n("Resize", ["x", "roi", "scales"], ["rs"], attrs=[W.attr_str("mode", "nearest"), W.attr_str("coordinate_transformation_mode", "asymmetric"), W.attr_str("nearest_mode", "floor")]),
+             n("Resize", ["x", "roi", "", "sizes"], ["rz"], attrs=[W.attr_str("mode", "nearest"), W.attr_str("coordinate_transformation_mode", "asymmetric"), W.attr_str("nearest_mode", "floor")]),
+             n("GroupNormalization", ["x", "gg", "gb"], ["gn"], attrs=[W.attr_int("num_groups", 3), W.attr_float("epsilon", 1e-5)]),
+             n("LpNormalization", ["x"], ["lp"], attrs=[W.attr_int("axis", 1), W.attr_int("p", 2)]),
+             n("Mish", ["x"], ["mish"]), n("Celu", ["x"], ["celu"], attrs=[W.attr_float("alpha", 1.5)]), n("ThresholdedRelu", ["x"], ["thr"], attrs=[W.attr_float("alpha", 0.3)])]
+    outs = [("tu", F32, list(x.shape)), ("tl", F32, list(x.shape)), ("ge", F32, list(gidx.shape)), ("sc", F32, list(kv.shape)), ("rs", F32, [2, 6, 10, 21]), ("rz", F32, [2, 6, 10, 7]),
+            ("gn", F32, list(x.shape)), ("lp", F32, list(x.shape)), ("mish", F32, list(x.shape)), ("celu", F32, list(x.shape)), ("thr", F32, list(x.shape))]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"x": x, "kv": kv}, outs, opset=21)
+    np.testing.assert_array_equal(r["tu"], np.triu(x))
+    np.testing.assert_array_equal(r["tl"], np.tril(x, -1))
+    np.testing.assert_array_equal(r["ge"], np.take_along_axis(x, gidx, axis=2))
+    ref = kv.copy(); ref[0, 1, 2] = upd[0]; ref[0, 0, 8] = upd[1]; ref[0, 1, 0] = upd[2]
+    np.testing.assert_array_equal(r["sc"], ref)
+    np.testing.assert_array_equal(r["rs"], np.repeat(np.repeat(x, 2, axis=2), 3, axis=3))
+    np.testing.assert_array_equal(r["rz"], np.repeat(x, 2, axis=2))
+    np.testing.assert_allclose(r["gn"], Fn.group_norm(torch.from_numpy(x).double(), 3, torch.from_numpy(gg).double(), torch.from_numpy(gb).double(), 1e-5).numpy(), rtol=2e-5, atol=2e-5)
+    np.testing.assert_allclose(r["lp"], x / np.sqrt((x.astype(np.float64) ** 2).sum(1, keepdims=True)), rtol=2e-5, atol=1e-6)
+    xd = x.astype(np.float64)
+    np.testing.assert_allclose(r["mish"], xd * np.tanh(np.log1p(np.exp(xd))), rtol=2e-5, atol=2e-6)
+    np.testing.assert_allclose(r["celu"], np.maximum(0, xd) + np.minimum(0, 1.5 * (np.exp(xd / 1.5) - 1)), rtol=2e-5, atol=2e-6)
+    np.testing.assert_array_equal(r["thr"], np.where(x > 0.3, x, 0))

@@ -96,5 +96,5 @@ def test_executor_operator_table(q3):
     for op in ("Conv", "ConvTranspose", "MatMul", "Gemm", "LayerNormalization", "Softmax", "Gather", "Slice", "Concat", "Reshape", "Shape", "Where", "ArgMin", "Pad", "Elu", "Erf",
                "CumSum", "Range", "ConstantOfShape", "Expand", "Tile", "ReduceMean", "InstanceNormalization", "BatchNormalization", "Split", "Cast", "Clip", "Pow"):
         assert Q.onnx_op_executable(op), op
-    for op in ("LSTM", "GRU", "Resize", "Einsum", "ScatterND", "TopK", "NonZero", "NotAnOp"):
+    for op in ("LSTM", "GRU", "Einsum", "TopK", "NonZero", "NotAnOp"):
         assert not Q.onnx_op_executable(op), op
