@@ -35,6 +35,7 @@ struct GemmArgs {
     // redoing two conversions + a subtraction per element for every tap and every column tile (SQ counters: the VALU was 57 % busy in the
     // N = 96 stage, the matrix pipe 20 %; profiles/r02_codec_sq_counters.md).  Kernels without an f16 path read hi + lo back as f32.
     int a_split, o_split;
+    int xcd_swizzle;   // k_conv_gemm_h3: XCD-aware tile order (Q3_CODEC_XCD=0 turns it off)
 };
 #define SEG_NONE 0x3fffffff
 
@@ -280,7 +281,17 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
     __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
+    // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in launch order, so the column tiles of one row tile (and neighbouring row tiles, which
+    // share the taps' halo rows) would land on 8 different private L2s and each fetch the activations from HBM again (measured: 532 MB per launch for a 63 MB
+    // activation tensor at N = 192).  The remap gives every XCD one contiguous range of tiles (bijective for any workgroup count).
+    int tile_m = blockIdx.y, tile_n = blockIdx.x;
+    if (g.xcd_swizzle) {
+        const int nwg = gridDim.x * gridDim.y, orig = blockIdx.y * gridDim.x + blockIdx.x;
+        const int xcd = orig & 7, q8 = nwg >> 3, r8 = nwg & 7;
+        const int wgid = (xcd < r8 ? xcd * (q8 + 1) : r8 * (q8 + 1) + (xcd - r8) * q8) + (orig >> 3);
+        tile_n = wgid % gridDim.x; tile_m = wgid / gridDim.x;
+    }
+    const int m0 = tile_m * BM, n0 = tile_n * BN;
     const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
     f32x16 acc[MR][NT];
 #pragma unroll
@@ -755,6 +766,8 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         }
         return;
     }
+    static const int xcd_on = [] { const char* e = std::getenv("Q3_CODEC_XCD"); return e ? atoi(e) : 1; }();
+    g.xcd_swizzle = xcd_on;
     static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
