@@ -959,15 +959,15 @@ __global__ void k_copy_rows(const float* __restrict__ src, float* __restrict__ d
 // all convolutions' histories in one launch (blockIdx.z = conv): a pass loads every history up front and saves every one at the end
 struct HistDesc { float* work; float* hist; int H, C, T, pad; };
 struct HistTable { HistDesc d[48]; int n; };
-__global__ void k_hist_all(HistTable tab, const int64_t* __restrict__ meta, int save) {
+__global__ void k_hist_all(HistTable tab, const int64_t* __restrict__ meta, int save) { // 4 floats per thread (every C is a multiple of 4)
     const HistDesc e = tab.d[blockIdx.z];
     const int g = blockIdx.y;
-    const size_t n = (size_t)e.H * e.C, i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    const size_t n = (size_t)e.H * e.C, i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4;
     if (i >= n) return;
     float* w = e.work + (size_t)g * (e.H + e.T) * e.C;
     float* h = e.hist + (size_t)meta[g] * n;
-    if (save) h[i] = w[(size_t)e.T * e.C + i]; // the last H rows of (history + new rows) become the next call's history
-    else w[i] = h[i];
+    if (save) *reinterpret_cast<float4*>(h + i) = *reinterpret_cast<const float4*>(w + (size_t)e.T * e.C + i); // the last H rows of (history + new rows) become the next call's history
+    else *reinterpret_cast<float4*>(w + i) = *reinterpret_cast<const float4*>(h + i);
 }
 // a stream's histories back to zero (new utterance): one launch for every convolution instead of one memset node per history (37 per request)
 __global__ void k_hist_zero(HistTable tab, int stream) {
@@ -1109,12 +1109,13 @@ struct CodecDecoder::Impl {
     void plan_hist(const Ext& e, int T) {
         if (e.H == 0) return;
         Q3_CHECK(table.n < 48, "too many streaming convolutions");
+        Q3_CHECK(e.C % 4 == 0, "streaming state rows must be a multiple of 4 channels (k_hist_all moves float4s)");
         table.d[table.n++] = HistDesc{work(e), e.hist.p, e.H, e.C, T, 0};
     }
     void move_hist(hipStream_t st, int G, const int64_t* meta, bool save) {
         size_t mx = 0;
         for (int i = 0; i < table.n; i++) mx = std::max(mx, (size_t)table.d[i].H * table.d[i].C);
-        hipLaunchKernelGGL(k_hist_all, dim3((unsigned)((mx + 255) / 256), G, table.n), dim3(256), 0, st, table, meta, save ? 1 : 0);
+        hipLaunchKernelGGL(k_hist_all, dim3((unsigned)((mx / 4 + 255) / 256), G, table.n), dim3(256), 0, st, table, meta, save ? 1 : 0);
     }
 
     void snake(hipStream_t st, const Snake& s, const float* src, float* dst, int rows, RowMap dm, bool split = false) {
