@@ -411,7 +411,10 @@ def main(argv=None):
         elif is_float:
             kname, kkey = "q3::k_gateup_float_mfma16 / k_gemm_float_mfma (talker gate/up, K = 1 f32 MFMA chains)", "k_gateup_float"
         else:
-            kname, kkey = "q3::k_gemm_q8_mfma<GU> (talker gate/up GEMM + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_q8_mfma<true>"
+            if args.quant == "q5_k_m":
+                kname, kkey = "q3::k_gemm_kq_mfma<GU, Q5_K> (talker gate/up GEMM on packed K-quant planes + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_kq_mfma<true"
+            else:
+                kname, kkey = "q3::k_gemm_q8_mfma<GU> (talker gate/up GEMM + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_q8_mfma<true>"
         # dominant kernel by algorithmic bytes AND by share of the batched step: the talker's gate/up launch (12288 rows x 2048 x 1.0625 B
         # = 26.7 MB of Q8_0 weights per launch, 28 launches per frame step)
         roof = {"bound": "hbm", "kernel": "%s; %d launches" % (kname, si["gu_launches"]),
