@@ -291,6 +291,12 @@ int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, in
                      const uint16_t* xd, int32_t ntok, float* y /* [ntok][n] */, int32_t lpr);
 /* batched layer path (>= 16 tokens): fused gate/up GEMM on the matrix cores + SwiGLU + int8 quantisation; w = [2*ff][k] Q8_0 rows
  * (gate rows first), k = 1024 or 2048; aq [ntok][ff], ad [ntok][ff/32] */
+/* K-quant forms of the two entries above: the matrix is built from up to 3 tensors (raw GGUF rows of ggml type 8 = Q8_0, 13 = Q5_K, 14 = Q6_K; row counts
+ * multiples of 32) into packed planes exactly as the engine does at load; >= 16 tokens with lpr = 0 take the matrix-core kernel (k_gemm_kq_mfma). */
+int q3tts_op_gemv_kq(const void* const* raws, const int32_t* types, const int32_t* rows, int32_t nparts, int32_t k, const int8_t* xq, const uint16_t* xd,
+                     int32_t ntok, float* y, int32_t lpr);
+int q3tts_op_gateup_kq(const void* gate_raw, const void* up_raw, int32_t type, int32_t ff, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok,
+                       int8_t* aq, uint16_t* ad);
 int q3tts_op_gateup_q8(const void* w_q8_0, int32_t ff, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok, int8_t* aq,
                        uint16_t* ad);
 /* float-weight matmul (spec S3 float form; ggml types 0 = f32, 1 = f16, 30 = bf16): ntok >= 12 runs the matrix-core kernel,

@@ -54,6 +54,53 @@ int q3tts_op_gateup_q8(const void* w, int32_t ff, int32_t k, const int8_t* xq, c
     Q3_API_END(Q3TTS_ERR)
 }
 
+int q3tts_op_gemv_kq(const void* const* raws, const int32_t* types, const int32_t* rows, int32_t nparts, int32_t k, const int8_t* xq, const uint16_t* xd,
+                     int32_t ntok, float* y, int32_t lpr) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(raws && types && rows && nparts >= 1 && nparts <= 3 && xq && xd && y && ntok >= 1 && k % 256 == 0, "bad K-quant gemv arguments");
+    KqPart parts[3];
+    int n = 0;
+    for (int i = 0; i < nparts; i++) { parts[i] = KqPart{raws[i], types[i], rows[i]}; n += rows[i]; }
+    DevBuf<uint8_t> storage;
+    Q8Mat m = kqmat_from_host(parts, nparts, k, storage);
+    DevBuf<int8_t> dxq((size_t)ntok * k); dxq.upload(xq, dxq.n);
+    DevBuf<uint16_t> dxd((size_t)ntok * (k / 32)); dxd.upload(xd, dxd.n);
+    const int nsseg = ((k >> 8) + 7) / 8;
+    DevBuf<float> parts_out((size_t)nsseg * ntok * n);
+    launch_gemv_q8(0, m, 0, n, dxq.p, dxd.p, parts_out.p, n, ntok, lpr);
+    Q3_LAUNCH_CHECK();
+    Q3_HIP(hipDeviceSynchronize());
+    std::vector<float> hp(parts_out.n);
+    parts_out.download(hp.data(), hp.size());
+    for (int t = 0; t < ntok; t++)
+        for (int r = 0; r < n; r++) { // spec S3: super-segment sums added in order
+            float v = hp[((size_t)0 * ntok + t) * n + r];
+            for (int s2 = 1; s2 < nsseg; s2++) v = v + hp[((size_t)s2 * ntok + t) * n + r];
+            y[(size_t)t * n + r] = v;
+        }
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+int q3tts_op_gateup_kq(const void* gate_raw, const void* up_raw, int32_t type, int32_t ff, int32_t k, const int8_t* xq, const uint16_t* xd, int32_t ntok,
+                       int8_t* aq, uint16_t* ad) {
+    Q3_API_BEGIN
+    require_gpu();
+    Q3_CHECK(gate_raw && up_raw && xq && xd && aq && ad && ff > 0 && ff % 32 == 0 && k % 256 == 0 && ntok >= 1, "bad gate/up shape");
+    KqPart parts[2] = {KqPart{gate_raw, type, ff}, KqPart{up_raw, type, ff}};
+    DevBuf<uint8_t> storage;
+    Q8Mat m = kqmat_from_host(parts, 2, k, storage);
+    DevBuf<int8_t> dxq((size_t)ntok * k); dxq.upload(xq, dxq.n);
+    DevBuf<uint16_t> dxd((size_t)ntok * (k / 32)); dxd.upload(xd, dxd.n);
+    DevBuf<int8_t> daq((size_t)ntok * ff); DevBuf<uint16_t> dad((size_t)ntok * (ff / 32));
+    if (!launch_gateup_mfma(0, m, ff, dxq.p, dxd.p, daq.p, dad.p, ntok)) throw Error("shape not served by the fused gate/up matrix-core kernel");
+    Q3_LAUNCH_CHECK();
+    Q3_HIP(hipDeviceSynchronize());
+    daq.download(aq, daq.n); dad.download(ad, dad.n);
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
+
 int q3tts_op_matmul_float(const void* w, int32_t type, int32_t n, int32_t k, int32_t row0, int32_t nrows, const float* x, int32_t ntok, float* y) {
     Q3_API_BEGIN
     require_gpu();

@@ -116,6 +116,56 @@ Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& stora
     return m;
 }
 
+Q8Mat kqmat_from_host(const KqPart* parts, int nparts, int k, DevBuf<uint8_t>& storage) {
+    Q3_CHECK(parts && nparts >= 1 && nparts <= 3 && k % 256 == 0, "bad K-quant matrix description");
+    Q8Mat m;
+    int n = 0;
+    for (int i = 0; i < nparts; i++) { Q3_CHECK(parts[i].rows > 0 && parts[i].rows % 32 == 0, "tensor rows must be a multiple of 32"); n += parts[i].rows; }
+    m.N = n; m.Npad = n; m.K = k;
+    const int nrg = n / 32;
+    std::vector<uint8_t> types((size_t)nrg);
+    std::vector<uint32_t> off((size_t)nrg);
+    size_t qs_bytes = 0;
+    { int rg = 0; for (int i = 0; i < nparts; i++) for (int j = 0; j < parts[i].rows / 32; j++, rg++) { types[(size_t)rg] = (uint8_t)parts[i].type; off[(size_t)rg] = (uint32_t)(qs_bytes / 16); qs_bytes += q3_rowgroup_bytes(parts[i].type, k); } }
+    const size_t sc_bytes = (size_t)n * (k / 32) * 2, meta_bytes = (size_t)n * (k / 256) * 16, ty_bytes = (size_t)((nrg + 15) & ~15), off_bytes = (size_t)((nrg * 4 + 15) & ~15);
+    storage.alloc(qs_bytes + sc_bytes + meta_bytes + ty_bytes + off_bytes);
+    storage.zero();
+    uint8_t* base = storage.p;
+    uint16_t* sc = reinterpret_cast<uint16_t*>(base + qs_bytes);
+    uint8_t* meta = base + qs_bytes + sc_bytes;
+    uint8_t* ty = meta + meta_bytes;
+    uint32_t* offd = reinterpret_cast<uint32_t*>(ty + ty_bytes);
+    Q3_HIP(hipMemcpy(ty, types.data(), types.size(), hipMemcpyHostToDevice));
+    Q3_HIP(hipMemcpy(offd, off.data(), off.size() * 4, hipMemcpyHostToDevice));
+    m.qs = base; m.sc = sc; m.meta = meta; m.rg_type = ty; m.rg_off = offd; m.qbytes = qs_bytes;
+    int last = -1, row_off = 0;
+    for (int i = 0; i < nparts; i++) {
+        const int t = parts[i].type, rows = parts[i].rows;
+        Q3_CHECK(t == Q3_T_Q8_0 || t == Q3_T_Q5_K || t == Q3_T_Q6_K, "unsupported weight type");
+        if (t != last) {
+            const int rg0 = row_off / 32;
+            if (m.nparts == 0) { m.p0_type = t; m.p0_off = off[(size_t)rg0]; }
+            else if (m.nparts == 1) { m.p1_rg0 = rg0; m.p1_type = t; m.p1_off = off[(size_t)rg0]; }
+            else { m.p2_rg0 = rg0; m.p2_type = t; m.p2_off = off[(size_t)rg0]; }
+            m.nparts++; last = t;
+        }
+        const size_t raw_bytes = t == Q3_T_Q8_0 ? (size_t)rows * (k / 32) * 34 : (size_t)rows * (k / 256) * (t == Q3_T_Q5_K ? 176 : 210);
+        DevBuf<uint8_t> raw(raw_bytes);
+        raw.upload((const uint8_t*)parts[i].raw, raw_bytes);
+        if (t == Q3_T_Q8_0) {
+            const size_t nblk = (size_t)rows * (k / 32);
+            hipLaunchKernelGGL(k_repack_q8, dim3((unsigned)((nblk + 255) / 256)), dim3(256), 0, 0, raw.p, rows, k, 0, base + (size_t)off[(size_t)(row_off / 32)] * 16, sc, row_off);
+        } else {
+            const size_t nsb = (size_t)rows * (k / 256);
+            if (t == Q3_T_Q5_K) hipLaunchKernelGGL(k_repack_q5k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, rows, k, row_off, base, offd, sc, meta);
+            else hipLaunchKernelGGL(k_repack_q6k, dim3((unsigned)((nsb + 255) / 256)), dim3(256), 0, 0, raw.p, rows, k, row_off, base, offd, sc, meta);
+        }
+        Q3_HIP(hipDeviceSynchronize());
+        row_off += rows;
+    }
+    return m;
+}
+
 Q8Mat Transformer::make_mat(const Gguf& g, const std::vector<std::pair<std::string, int>>& rows, int N, int K) {
     Q3_CHECK(K % 256 == 0, "K must be a multiple of 256");
     Q8Mat m;

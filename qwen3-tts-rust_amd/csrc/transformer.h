@@ -101,6 +101,10 @@ private:
 
 // standalone repack of host GGUF Q8_0 rows into a device Q8Mat (storage owns the memory); used by parity ops
 Q8Mat q8mat_from_host(const void* raw_q8_0, int n, int k, DevBuf<uint8_t>& storage);
+// the same for a K-quant matrix built from up to 3 tensors (GGUF rows of type Q8_0 / Q5_K / Q6_K, row counts multiples of 32): packed planes + tensor map,
+// exactly what Transformer::make_mat produces (op-level parity tests)
+struct KqPart { const void* raw; int type; int rows; };
+Q8Mat kqmat_from_host(const KqPart* parts, int nparts, int k, DevBuf<uint8_t>& storage);
 
 // simple paged KV pool (pages of 64 positions) -- "paged KV cache sized for 288 GB HBM3E"
 class KvPool {

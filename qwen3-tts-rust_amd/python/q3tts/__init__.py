@@ -72,7 +72,7 @@ SYMBOLS = [
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
     "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
     "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
-    "q3tts_text_nfc", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
+    "q3tts_text_nfc", "q3tts_op_gemv_kq", "q3tts_op_gateup_kq", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
@@ -650,6 +650,31 @@ class OnnxDecoder:
         n = C.c_int64()
         _chk(lib().q3tts_onnx_decoder_decode(self.h, codes.ctypes.data, codes.shape[0], 1 if is_final else 0, out.ctypes.data, out.size, C.byref(n)))
         return out[: n.value].copy()
+
+
+def op_gemv_kq(parts, k, xq, xd, lpr=0):
+    """parts: [(raw bytes ndarray, ggml type, rows)] -> y [ntok, sum rows] through the K-quant GEMV / matrix-core GEMM"""
+    L = lib()
+    L.q3tts_op_gemv_kq.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_int32]
+    raws = [np.ascontiguousarray(p[0]) for p in parts]
+    ptrs = (C.c_void_p * len(parts))(*[r.ctypes.data for r in raws])
+    types = np.asarray([p[1] for p in parts], np.int32); rows = np.asarray([p[2] for p in parts], np.int32)
+    xq = np.ascontiguousarray(xq, np.int8); xd = np.ascontiguousarray(xd, np.uint16)
+    ntok = xq.shape[0]
+    y = np.zeros((ntok, int(rows.sum())), np.float32)
+    _chk(L.q3tts_op_gemv_kq(ptrs, types.ctypes.data, rows.ctypes.data, len(parts), k, xq.ctypes.data, xd.ctypes.data, ntok, y.ctypes.data, lpr))
+    return y
+
+
+def op_gateup_kq(gate_raw, up_raw, qtype, ff, k, xq, xd):
+    L = lib()
+    L.q3tts_op_gateup_kq.argtypes = [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p]
+    g = np.ascontiguousarray(gate_raw); u = np.ascontiguousarray(up_raw)
+    xq = np.ascontiguousarray(xq, np.int8); xd = np.ascontiguousarray(xd, np.uint16)
+    ntok = xq.shape[0]
+    aq = np.zeros((ntok, ff), np.int8); ad = np.zeros((ntok, ff // 32), np.uint16)
+    _chk(L.q3tts_op_gateup_kq(g.ctypes.data, u.ctypes.data, qtype, ff, k, xq.ctypes.data, xd.ctypes.data, ntok, aq.ctypes.data, ad.ctypes.data))
+    return aq, ad
 
 
 def text_nfc(text):

@@ -47,6 +47,78 @@ def test_gemv_q8_bit_exact(gpu, oracle, n, k, ntok):
         assert np.array_equal(_bits(gpu.op_gemv_q8(raw, n, k, xq, xd, lpr)), _bits(yo)), lpr
 
 
+def _rand_kq_rows(rng, qtype, n, k):
+    """n rows of k weights as raw GGUF blocks with RANDOM fields (every bit pattern of quants, scales and mins is a valid block): harsher than weights
+    quantised from a Gaussian -- negative / extreme Q6_K sub-block scales, all 6 bits of the Q5_K scales and mins, dense high-bit planes"""
+    nsb = n * (k // 256)
+    f16 = lambda lo, hi: (rng.uniform(lo, hi, nsb).astype(np.float16)).view(np.uint16)
+    if qtype == 8:
+        blk = np.zeros((n * (k // 32), 34), np.uint8)
+        blk[:, :2] = (rng.uniform(0.001, 0.05, n * (k // 32)).astype(np.float16)).view(np.uint16).view(np.uint8).reshape(-1, 2)
+        blk[:, 2:] = rng.integers(0, 256, (n * (k // 32), 32), dtype=np.uint8)
+        return blk.reshape(-1)
+    if qtype == 13:  # {f16 d, dmin; u8 scales[12]; u8 qh[32]; u8 qs[128]}
+        blk = rng.integers(0, 256, (nsb, 176), dtype=np.uint8)
+        blk[:, 0:2] = f16(0.0005, 0.01).view(np.uint8).reshape(-1, 2); blk[:, 2:4] = f16(0.0005, 0.01).view(np.uint8).reshape(-1, 2)
+        return blk.reshape(-1)
+    blk = rng.integers(0, 256, (nsb, 210), dtype=np.uint8)  # {u8 ql[128]; u8 qh[64]; i8 scales[16]; f16 d}
+    blk[:, 208:210] = f16(0.0002, 0.004).view(np.uint8).reshape(-1, 2)
+    return blk.reshape(-1)
+
+
+def _oracle_rows(L, qtype, raw, n, k, xq, xd):
+    y = np.zeros((xq.shape[0], n), np.float32)
+    for t in range(xq.shape[0]):
+        L.q3o_matvec(qtype, raw.ctypes.data, n, k, xq[t].ctypes.data, xd[t].ctypes.data, None, y[t].ctypes.data)
+    return y
+
+
+@pytest.mark.parametrize("k,ntok", [(256, 1), (1024, 3), (2048, 8), (3072, 12), (2048, 17), (1024, 64), (3072, 33), (6144, 64), (2048, 70)])
+def test_kquant_gemv_and_matrix_core_gemm_bit_exact(gpu, oracle, k, ntok):
+    """Packed K-quant planes at the op level, random block contents: Q5_K, Q6_K, Q8_0 and a fused three-tensor matrix (Q5_K + Q6_K + Q8_0 row groups, the
+    per-workgroup type dispatch) through every lanes-per-row form of the GEMV and, from 16 tokens, the matrix-core GEMM (k_gemm_kq_mfma) -- against
+    the oracle's block arithmetic (q3o_matvec on the raw GGUF rows), bit for bit."""
+    rng = np.random.default_rng(1000 + k + ntok)
+    L = oracle.lib()
+    x = (rng.standard_normal((ntok, k)) * rng.uniform(0.1, 4)).astype(np.float32)
+    xq = np.zeros((ntok, k), np.int8); xd = np.zeros((ntok, k // 32), np.uint16)
+    for t in range(ntok):
+        L.q3o_quant_act(x[t].ctypes.data, k, xq[t].ctypes.data, xd[t].ctypes.data)
+    raws = {q: _rand_kq_rows(rng, q, 96, k) for q in (13, 14, 8)}
+    refs = {q: _oracle_rows(L, q, raws[q], 96, k, xq, xd) for q in (13, 14, 8)}
+    for lpr in (2, 4, 8, 0):
+        for q in (13, 14):
+            got = gpu.op_gemv_kq([(raws[q], q, 96)], k, xq, xd, lpr)
+            assert np.array_equal(_bits(got), _bits(refs[q])), (q, lpr)
+        got = gpu.op_gemv_kq([(raws[13], 13, 96), (raws[14], 14, 96), (raws[8], 8, 96)], k, xq, xd, lpr)   # q, k (Q5_K) + v (Q6_K) style fusion, plus Q8_0 rows
+        assert np.array_equal(_bits(got), _bits(np.concatenate([refs[13], refs[14], refs[8]], 1))), ("mixed", lpr)
+
+
+@pytest.mark.parametrize("qtype,ff,k,ntok", [(13, 3072, 1024, 64), (13, 6144, 2048, 33), (14, 3072, 1024, 40), (14, 512, 2048, 130), (13, 512, 2048, 16)])
+def test_kquant_gateup_matrix_core_bit_exact(gpu, oracle, qtype, ff, k, ntok):
+    """the fused gate / up + SwiGLU + int8 quantisation form of k_gemm_kq_mfma (two passes over the token tiles, gate sums parked in LDS) at the full
+    model's shapes, random Q5_K / Q6_K blocks; oracle: matvec rows -> q3_swiglu -> quant_act"""
+    import ctypes as C
+    rng = np.random.default_rng(qtype + ff + k + ntok)
+    L = oracle.lib()
+    L.q3o_spec_swiglu_vec.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]
+    gate, up = _rand_kq_rows(rng, qtype, ff, k), _rand_kq_rows(rng, qtype, ff, k)
+    x = (rng.standard_normal((ntok, k)) * rng.uniform(0.5, 3)).astype(np.float32)
+    xq = np.zeros((ntok, k), np.int8); xd = np.zeros((ntok, k // 32), np.uint16)
+    eq = np.zeros((ntok, ff), np.int8); ed = np.zeros((ntok, ff // 32), np.uint16)
+    g = np.zeros(ff, np.float32); u = np.zeros(ff, np.float32)
+    for t in range(ntok):
+        L.q3o_quant_act(x[t].ctypes.data, k, xq[t].ctypes.data, xd[t].ctypes.data)
+        L.q3o_matvec(qtype, gate.ctypes.data, ff, k, xq[t].ctypes.data, xd[t].ctypes.data, None, g.ctypes.data)
+        L.q3o_matvec(qtype, up.ctypes.data, ff, k, xq[t].ctypes.data, xd[t].ctypes.data, None, u.ctypes.data)
+        a = np.zeros(ff, np.float32)
+        L.q3o_spec_swiglu_vec(g.ctypes.data, u.ctypes.data, ff, a.ctypes.data)
+        L.q3o_quant_act(a.ctypes.data, ff, eq[t].ctypes.data, ed[t].ctypes.data)
+    aq, ad = gpu.op_gateup_kq(gate, up, qtype, ff, k, xq, xd)
+    assert np.array_equal(ad, ed)
+    assert np.array_equal(aq, eq)
+
+
 @pytest.mark.parametrize("ff,k,ntok", [(3072, 1024, 64), (6144, 2048, 64), (6144, 2048, 33), (3072, 1024, 130), (512, 2048, 16)])
 def test_gateup_mfma_bit_exact(gpu, oracle, ff, k, ntok):
     """fused gate/up GEMM + SwiGLU + int8 quantisation on the matrix cores (the batched layer path of configs C3 / 256 slots) at the
