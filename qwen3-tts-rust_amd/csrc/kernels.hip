@@ -146,7 +146,7 @@ template <bool GU, int TS, int WPE>
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
 k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
-static int q8_scale_mfma() { static const int m = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? atoi(e) : 1; }(); return m; } // 0 LDS scales, 1 pair tiles, 2 / 3 per-block tiles (4 / 8 activation blocks in flight)
+static int q8_scale_mfma() { static const int m = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? atoi(e) : 1; }(); return m; } // 0: scales through LDS, 1: scale tiles from the f32 matrix pipe
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
     const int ntiles = (ntok + 31) / 32;
@@ -280,7 +280,7 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
         if (tail && tail->counters && 64 * nw >= 64 * (tail->d >> 8) && (tail->d & 255) == 0 && tail->d <= 2048 && !tail->a.idx_keys) { nt = *tail; if (tail_fused) *tail_fused = true; }
 #define Q3_MF(SMV) hipLaunchKernelGGL((k_gemm_q8_mfma<false, SMV>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, \
                                      out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr, nt)
-        switch (q8_scale_mfma()) { case 0: Q3_MF(0); break; case 2: Q3_MF(2); break; case 3: Q3_MF(3); break; default: Q3_MF(1); }
+        if (q8_scale_mfma()) Q3_MF(1); else Q3_MF(0);
 #undef Q3_MF
         return;
     }
@@ -326,7 +326,7 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
 #define Q3_MG(SMV) hipLaunchKernelGGL((k_gemm_q8_mfma<true, SMV>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad, NormTail{})
-    switch (q8_scale_mfma()) { case 0: Q3_MG(0); break; case 2: Q3_MG(2); break; case 3: Q3_MG(3); break; default: Q3_MG(1); }
+    if (q8_scale_mfma()) Q3_MG(1); else Q3_MG(0);
 #undef Q3_MG
     return true;
 }
@@ -416,7 +416,6 @@ typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
 typedef float f32x32q __attribute__((ext_vector_type(32)));
-typedef float f32x16s __attribute__((ext_vector_type(16)));
 // The workgroup keeps its weight tile (32 rows x one super-segment) in registers and loops over 32-token tiles
 // (tile = blockIdx.z, += gridDim.z), so weights are streamed once per launch when gridDim.z = 1.
 // GU = gate/up form for K <= 2048: pass 0 runs the 32 gate rows over the workgroup's tiles and parks the sums in LDS, pass 1
@@ -426,7 +425,7 @@ typedef float f32x16s __attribute__((ext_vector_type(16)));
 // f32, and it is an outer product -- one v_mfma_f32_32x32x1_2b_f32 (K = 1: one exact product per output, C = 0) delivers the scale tiles of
 // two blocks in the C layout of the int8 MFMA.  That takes the 8 v_pk_mul_f32 + 4 ds_read_b128 per block and the LDS staging round (with
 // its barrier) off the VALU-bound chain; same bits (the product was exact before, too).
-template <bool GU, int SM> // SM: 0 = scales through LDS, 1 = one f32 MFMA per block PAIR (2 activation blocks in flight in the gate/up form), 2 / 3 = one per block (4 / 8 in flight)
+template <bool GU, int SM> // SM: 0 = scales through LDS, 1 = one f32 MFMA per block pair
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                                                       int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad, NormTail tail) {
@@ -479,27 +478,20 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
                 f32x2v acc2[8];
 #pragma unroll
                 for (int g = 0; g < 8; g++) acc2[g] = f32x2v{0.0f, 0.0f};
-                // activation blocks fetched at a time.  The pair form (SM = 1) holds a 32-register scale tile, which leaves room for 2 blocks in the gate/up
-                // kernel: four exposed L2 round trips per token tile.  A per-block scale tile (v_mfma_f32_32x32x2_f32 with the k = 1 lanes fed 0: 16 registers, same
-                // exact products) frees the registers for 4 or 8 blocks in flight.
-                constexpr int AB = SM == 3 ? 8 : SM == 2 ? 4 : (SM && GU) ? 2 : 4;
+                // activation blocks fetched at a time: 2 in the gate/up form keeps the kernel inside 128 VGPRs without spilling.  (A per-block 16-register scale
+                // tile -- v_mfma_f32_32x32x2_f32 with the second k fed zeros -- frees registers for 4 or 8 blocks in flight; built and measured in round 2: C3 612 / 548
+                // vs 616 audio-s/s, the fetch latency is already hidden by the SIMD's other waves, so it was removed again.)
+                constexpr int AB = (SM && GU) ? 2 : 4;
 #pragma unroll
                 for (int ih = 0; ih < 8 / AB; ih++) {
                     i32x4v av[AB];
 #pragma unroll
                     for (int i = 0; i < AB; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + (AB * ih + i) * 32);
                     f32x32q D;
-                    f32x16s D1;
 #pragma unroll
                     for (int i4 = 0; i4 < AB; i4++) {
                         const int i = AB * ih + i4;
-                        if (SM >= 2) { // scale tile of block i alone: K = 2 with the second k (lanes 32..63) zero
-#pragma unroll
-                            for (int g = 0; g < 16; g++) D1[g] = 0.0f;
-                            const float ex1 = half ? 0.0f : h2f(half_of(dxa, i)), ew1 = half ? 0.0f : h2f(half_of(dwv, i));
-                            D1 = __builtin_amdgcn_mfma_f32_32x32x2f32(ex1, ew1, D1, 0, 0, 0);
-                        }
-                        if (SM == 1 && (i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
+                        if (SM && (i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
 #pragma unroll
                             for (int g = 0; g < 32; g++) D[g] = 0.0f;
                             const uint32_t ex = half ? half_of(dxa, i + 1) : half_of(dxa, i), ew = half ? half_of(dwv, i + 1) : half_of(dwv, i);
@@ -514,9 +506,7 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 #pragma unroll
                         for (int g4 = 0; g4 < 4; g4++) {
                             f32x2v sc_a, sc_b;
-                            if (SM >= 2) {
-                                sc_a = f32x2v{D1[4 * g4], D1[4 * g4 + 1]}; sc_b = f32x2v{D1[4 * g4 + 2], D1[4 * g4 + 3]};
-                            } else if (SM == 1) {
+                            if (SM) {
                                 const int o = 16 * (i4 & 1) + 4 * g4;
                                 sc_a = f32x2v{D[o], D[o + 1]}; sc_b = f32x2v{D[o + 2], D[o + 3]};
                             } else {
