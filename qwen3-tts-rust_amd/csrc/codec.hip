@@ -269,7 +269,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 // fragments for 3 NT matrix instructions (NT = 3: 8 for 9, against 4 for 3 in k_conv_gemm_h<1>), a 96-column stage has no padded columns
 // (BN = 64 wastes a quarter of the matrix work at N = 96) and the activation tile is fetched once per 96 output columns instead of once per 64.
 // One K tile in flight and ~110 VGPRs / 36 KB of LDS keep 4 workgroups per CU -- the middle ground between k_conv_gemm_h<1> (8 per CU, the
-// L2 -> LDS traffic 2.3 x larger) and k_conv_gemm_h2<2, 3> (2 per CU, spills).  Reads pre-split operands as copies.
+// L2 -> LDS traffic 2.3 x larger) and a 256 x 96 register-blocked tile (2 per CU, spills; removed).  Reads pre-split operands as copies.
 template <int MR, int NT, int BK>
 __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
     constexpr int BM = 128 * MR, BN = 32 * NT, LD = BK + 8; // LD: padded row stride (f16); 80 / 144 B keep the b128 fragment reads conflict-free
@@ -413,251 +413,6 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     if constexpr (MR > 1) epilogue_rows(acc[1], m0 + (wave * MR + 1) * 32);
     static_assert(MR <= 2, "one epilogue call per row tile");
 }
-// Register-blocked form of the split-f16 GEMM for large M: the 4 waves of a workgroup stack along M and each wave owns MR x NT tiles of
-// 32 x 32 (workgroup tile (128 MR) x (32 NT); MR = 2, NT = 3 -> 256 x 96, and every channel count of the decoder is 96 * 2^k, so no column of
-// a tile is padding).  Why: in k_conv_gemm_h<1> a wave reads 4 LDS fragments (a_hi, a_lo, b_hi, b_lo) for 3 matrix instructions -- the LDS
-// pipe (128 B/clk per CU) is busy longer than the matrix pipe, and every 64 x 64 output tile re-streams its 64-column weight panel (for the
-// N = 96 stage at 245 760 rows that is 1.3 GB of L2 -> LDS weight traffic per launch against 94 MB of activations).  Here a k-step of 16 reads
-// 2 MR + 2 NT = 10 fragments for 3 MR NT = 18 matrix instructions, and the weight panel is read once per 256 rows.
-template <int MR, int NT>
-__global__ void __launch_bounds__(256) k_conv_gemm_h2(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
-    constexpr int BM = 128 * MR, BN = 32 * NT, BK = 32, LD = 40;
-    constexpr int NA = BM * 8 / 256;             // float4 fetches of A per thread per K tile
-    constexpr int NB = (BN * 4 + 255) / 256;     // uint4 fetches of B (hi and lo each) per thread per K tile
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
-    const int ksplit = gridDim.z, kper = g.K / ksplit, kbeg = blockIdx.z * kper, kend = kbeg + kper;
-    f32x16 acc[MR][NT];
-#pragma unroll
-    for (int t = 0; t < MR; t++)
-#pragma unroll
-        for (int u = 0; u < NT; u++)
-#pragma unroll
-            for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
-    float4 ra[2][NA]; // two K tiles in flight (the second set hides the ~2 us HBM latency of the activations behind two compute steps)
-    uint4 rh[2][NB], rl[2][NB];
-    int arow[NA];
-#pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
-    auto fetch = [&](int k0, float4* ra_, uint4* rh_, uint4* rl_) {
-        const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            ra_[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) ra_[i] = *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
-        }
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            rh_[i] = make_uint4(0, 0, 0, 0); rl_[i] = make_uint4(0, 0, 0, 0);
-            if (e < BN * 4 && n0 + r < g.N) {
-                rh_[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
-                rl_[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
-            }
-        }
-    };
-    auto stash = [&](const float4* ra_, const uint4* rh_, const uint4* rl_) {
-#pragma unroll
-        for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            const float x[4] = {ra_[i].x, ra_[i].y, ra_[i].z, ra_[i].w};
-            h4v hi, lo;
-#pragma unroll
-            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
-            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
-            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
-        }
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            if (e < BN * 4) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh_[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl_[i]; }
-        }
-    };
-    auto compute = [&]() {
-#pragma unroll
-        for (int kk = 0; kk < BK; kk += 16) {
-            const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
-            h8v bh[NT], bl[NT];
-#pragma unroll
-            for (int u = 0; u < NT; u++) {
-                bh[u] = *reinterpret_cast<const h8v*>(&Bh[u * 32 + (lane & 31)][ko]);
-                bl[u] = *reinterpret_cast<const h8v*>(&Bl[u * 32 + (lane & 31)][ko]);
-            }
-#pragma unroll
-            for (int t = 0; t < MR; t++) {
-                const int ar = (wave * MR + t) * 32 + (lane & 31);
-                const h8v ah = *reinterpret_cast<const h8v*>(&Ah[ar][ko]);
-                const h8v al = *reinterpret_cast<const h8v*>(&Al[ar][ko]);
-#pragma unroll
-                for (int u = 0; u < NT; u++) {
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh[u], acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl[u], acc[t][u], 0, 0, 0);
-                    acc[t][u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh[u], acc[t][u], 0, 0, 0);
-                }
-            }
-        }
-    };
-    fetch(kbeg, ra[0], rh[0], rl[0]);
-    if (kbeg + BK < kend) fetch(kbeg + BK, ra[1], rh[1], rl[1]);
-    for (int k0 = kbeg; k0 < kend; k0 += 2 * BK) { // two K tiles per iteration so the register sets alternate at compile time
-        stash(ra[0], rh[0], rl[0]);
-        __syncthreads();
-        if (k0 + 2 * BK < kend) fetch(k0 + 2 * BK, ra[0], rh[0], rl[0]);
-        compute();
-        __syncthreads();
-        if (k0 + BK < kend) {
-            stash(ra[1], rh[1], rl[1]);
-            __syncthreads();
-            if (k0 + 3 * BK < kend) fetch(k0 + 3 * BK, ra[1], rh[1], rl[1]);
-            compute();
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NT; u++) {
-        const int col = n0 + u * 32 + (lane & 31);
-        if (col >= g.N) continue;
-#pragma unroll
-        for (int t = 0; t < MR; t++)
-#pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + (wave * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.M) {
-                    if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][u][r];
-                    else gemm_store(g, row, col, gemm_epilogue(g, acc[t][u][r], row, col));
-                }
-            }
-    }
-}
-// LDS-window form of the 7-tap dilated convolutions of the narrow decoder stages (cin = cout = C in {96, 192}; K = 7 C).
-// Why (profiles/r02_hbm_traffic_pmc.md, gpurun codec traces): the implicit-GEMM forms above walk K tap-major, so a workgroup sweeps its A rows
-// once per tap in 128-byte column strips and relies on L2 to keep them; at 245 760 rows the N = 96 stage fetches 395 MB from HBM per launch for
-// 94 MB of activations (and the 256 x 96 register-blocked tile, whose window no longer fits the L2 next to its neighbours', is bound by exactly
-// that: 2.4 TB/s of misses, 397 us).  Here a workgroup copies its BM + 6 dil input rows ONCE into LDS (as the hi / lo f16 planes the split-f16
-// MFMA needs), forms the 7 taps from that window, and streams only the (L2-resident, 258 KB / 1 MB) weights through a small LDS tile:
-// every input row is read once from HBM (plus the 6 dil halo rows per tile).  4 waves; C = 96: BM = 128, a wave owns 32 rows x all 96 columns;
-// C = 192: BM = 64, a wave owns 32 rows x 96 columns.  Same products, same accumulation structure per output as k_conv_gemm_h (f32 accumulate of
-// a_lo b_hi + a_hi b_lo + a_hi b_hi over K in the same K order), same epilogues.
-template <int C, int BM>
-__global__ void __launch_bounds__(256) k_conv7_win_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
-    constexpr int NCG = C / 96, NRT = BM / 32, NT = 3, BK = 32, LDB = 40;
-    static_assert(NCG * NRT == 4, "4 waves = row tiles x column groups");
-    constexpr int LDW = C + 8;                     // halfs per window row: 16-byte pad keeps the 8-lane groups of a b128 read on distinct banks
-    constexpr int WMAX = BM + 54;                  // dil <= 9
-    constexpr int NB = (C * 4 + 255) / 256;        // uint4 fetches of B (hi and lo each) per thread per K tile
-    extern __shared__ __attribute__((aligned(16))) unsigned char smem_w[];
-    _Float16* Ah = reinterpret_cast<_Float16*>(smem_w);                   // [WMAX][LDW]
-    _Float16* Al = Ah + (size_t)WMAX * LDW;                               // [WMAX][LDW]
-    _Float16* Bh = Al + (size_t)WMAX * LDW;                               // [C][LDB]
-    _Float16* Bl = Bh + (size_t)C * LDB;                                  // [C][LDB]
-    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    const int rt = wave % NRT, cg = wave / NRT;
-    const int m0 = blockIdx.x * BM;
-    const int wrows = BM + 6 * g.dil;
-    const size_t base_row = (size_t)m0 + (size_t)seg_of(m0, g.a_segT) * g.a_skip; // BM divides a_segT: the window is one contiguous run of the extended buffer
-    // With the window in LDS only ONE workgroup (one wave per SIMD) fits a CU, so nothing but the wave's own loads in flight hides latency:
-    // the weight tiles run DEPTH K tiles ahead in registers (K / 32 is a multiple of 3: K = 7 C, C = 96 or 192), and the window is fetched
-    // with ALL its loads issued before the first conversion (a rolled loop paid one ~2 us HBM round trip per iteration: 34 us per workgroup).
-    constexpr int DEPTH = 3;
-    uint4 rh[DEPTH][NB], rl[DEPTH][NB];
-    auto fetch_b = [&](int k0, uint4* rh_, uint4* rl_) {
-#pragma unroll
-        for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-            rh_[i] = make_uint4(0, 0, 0, 0); rl_[i] = make_uint4(0, 0, 0, 0);
-            if (e < C * 4 && k0 < g.K) {
-                rh_[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)r * g.K + k0 + wk);
-                rl_[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)r * g.K + k0 + wk);
-            }
-        }
-    };
-#pragma unroll
-    for (int d = 0; d < DEPTH; d++) fetch_b(d * BK, rh[d], rl[d]);
-    // the window: (BM + 6 dil) rows x C channels, f32 -> hi / lo f16, one pass over HBM
-    {
-        constexpr int NW = (WMAX * (C / 4) + 255) / 256;
-        float4 wv[NW];
-        const int nel = wrows * (C / 4);
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const int e = tid + i * 256, r = e / (C / 4), c4 = e % (C / 4);
-            wv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (e < nel) wv[i] = *reinterpret_cast<const float4*>(g.A + (base_row + r) * g.lda + 4 * c4);
-        }
-#pragma unroll
-        for (int i = 0; i < NW; i++) {
-            const int e = tid + i * 256, r = e / (C / 4), c4 = e % (C / 4);
-            const float x[4] = {wv[i].x, wv[i].y, wv[i].z, wv[i].w};
-            h4v hi, lo;
-#pragma unroll
-            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
-            if (e < nel) {
-                *reinterpret_cast<h4v*>(Ah + (size_t)r * LDW + 4 * c4) = hi;
-                *reinterpret_cast<h4v*>(Al + (size_t)r * LDW + 4 * c4) = lo;
-            }
-        }
-    }
-    f32x16 acc[NT];
-#pragma unroll
-    for (int u = 0; u < NT; u++)
-#pragma unroll
-        for (int i = 0; i < 16; i++) acc[u][i] = 0.0f;
-    for (int kb = 0; kb < g.K; kb += DEPTH * BK) {
-#pragma unroll
-        for (int d = 0; d < DEPTH; d++) {
-            const int k0 = kb + d * BK;
-#pragma unroll
-            for (int i = 0; i < NB; i++) {
-                const int e = tid + i * 256, r = e / 4, wk = 8 * (e & 3);
-                if (e < C * 4) { *reinterpret_cast<uint4*>(Bh + (size_t)r * LDB + wk) = rh[d][i]; *reinterpret_cast<uint4*>(Bl + (size_t)r * LDB + wk) = rl[d][i]; }
-            }
-            __syncthreads(); // (first iteration: also publishes the window)
-            fetch_b(k0 + DEPTH * BK, rh[d], rl[d]);
-            const int j = k0 / C, ci0 = k0 % C;      // tap, first channel of this K tile (BK divides C)
-            const int arow = rt * 32 + (lane & 31) + j * g.dil;
-#pragma unroll
-            for (int kk = 0; kk < BK; kk += 16) {
-                const int ko = kk + 8 * (lane >> 5);
-                const h8v ah = *reinterpret_cast<const h8v*>(Ah + (size_t)arow * LDW + ci0 + ko);
-                const h8v al = *reinterpret_cast<const h8v*>(Al + (size_t)arow * LDW + ci0 + ko);
-#pragma unroll
-                for (int u = 0; u < NT; u++) {
-                    const int brow = (cg * NT + u) * 32 + (lane & 31);
-                    const h8v bh = *reinterpret_cast<const h8v*>(Bh + (size_t)brow * LDB + ko);
-                    const h8v bl = *reinterpret_cast<const h8v*>(Bl + (size_t)brow * LDB + ko);
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, acc[u], 0, 0, 0);
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, acc[u], 0, 0, 0);
-                    acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[u], 0, 0, 0);
-                }
-            }
-            __syncthreads();
-        }
-    }
-#pragma unroll
-    for (int u = 0; u < NT; u++) {
-        const int col = (cg * NT + u) * 32 + (lane & 31);
-#pragma unroll
-        for (int r = 0; r < 16; r++) {
-            const int row = m0 + rt * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-            if (row < g.M) gemm_store(g, row, col, gemm_epilogue(g, acc[u][r], row, col));
-        }
-    }
-}
-template <int C, int BM> static size_t conv7_win_lds() { return ((size_t)(BM + 54) * (C + 8) * 2 + (size_t)C * 40 * 2) * sizeof(_Float16); }
-static void init_codec_kernel_attributes() { // dynamic LDS above 64 KiB needs a per-device opt-in (done at decoder construction)
-    static bool done[64] = {};
-    int dev = 0;
-    Q3_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev > 63 || done[dev]) return;
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7_win_h<96, 128>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv7_win_lds<96, 128>()));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_conv7_win_h<192, 64>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)conv7_win_lds<192, 64>()));
-    done[dev] = true;
-}
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i >= (size_t)g.M * g.N) return;
@@ -733,52 +488,12 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     while (tiles * ksplit < 256 && ksplit < 16 && (g.K / (ksplit * 2)) % 16 == 0 && g.K / (ksplit * 2) >= 128 &&
            (size_t)(ksplit * 2) * g.M * g.N <= ws_floats) ksplit *= 2;
     g.ws = ws;
-    // Opt-in (Q3_CODEC_H2_MINM=2048): measured on MI355X the register-blocked form LOSES to the 64 x 64 form -- codec alone at 32 streams
-    // 10.3 vs 6.8 ms per 4-frame pass (995 vs 1505 audio-s/s) with two K tiles in flight, 7.6 ms with one: 248 VGPRs and 56 KB of LDS leave two
-    // workgroups per CU, and a barrier-synchronous main loop with two workgroups cannot hide the ~2 us activation latency that eight
-    // 44-register workgroups of the small-tile form hide by sheer occupancy.  The big tile needs a barrier-free pipelined main loop to pay.
-    // 7-tap convolutions of the narrow stages: LDS-window form (every input row read once).  Opt-in (Q3_CODEC_WIN_MIN_WGS=256): parity-green and
-    // it does cut the HBM reads, but measured SLOWER than the small-tile form -- N = 96 at 245 760 rows 348 vs 268 us, N = 192 365 vs 238 us,
-    // codec alone at 32 streams 7.06 vs 6.64 ms per pass -- with the weight tiles 1, 3 or 7 K steps ahead, with the window loads rolled or all
-    // in flight, with libm or the short sine in the epilogue: a 91 / 125 KB window leaves ONE workgroup (one wave per SIMD) per CU, and one wave
-    // per SIMD cannot overlap its own LDS reads, matrix instructions, barriers and epilogue the way eight small workgroups overlap each other's.
-    static const int win_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_WIN_MIN_WGS"); return e ? atoi(e) : 0; }(); // 0 = never
-    if (wh && !g_codec_f32 && !g.a_split && !g.o_split && win_min_wgs > 0 && g.cin == g.N && g.K == 7 * g.cin && g.dil <= 9 && (g.N == 96 || g.N == 192)) {
-        const int bm = g.N == 96 ? 128 : 64;
-        if (g.M % bm == 0 && (g.a_segT == SEG_NONE || g.a_segT % bm == 0) && g.M / bm >= win_min_wgs) {
-            const size_t lds96 = conv7_win_lds<96, 128>(), lds192 = conv7_win_lds<192, 64>();
-            if (g.N == 96) hipLaunchKernelGGL((k_conv7_win_h<96, 128>), dim3(g.M / bm), dim3(256), lds96, st, g, wh, wl);
-            else hipLaunchKernelGGL((k_conv7_win_h<192, 64>), dim3(g.M / bm), dim3(256), lds192, st, g, wh, wl);
-            return;
-        }
-    }
-    static const int h2_min_m = [] { const char* e = std::getenv("Q3_CODEC_H2_MINM"); return e ? atoi(e) : 0; }(); // 0 = never
-    if (!small && wh && !g_codec_f32 && !g.a_split && !g.o_split && g.cin % 32 == 0 && h2_min_m > 0 && g.M >= h2_min_m && g.N % 96 == 0 &&
-        (g.N / 96) * ((g.M + 255) / 256) >= 128) { // register-blocked 256 x 96 tiles, when they still make >= 128 workgroups before split-K
-        const int t2 = (g.N / 96) * ((g.M + 255) / 256);
-        static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }();
-        int ks = 1;
-        while (t2 * ks < wg_target && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
-        hipLaunchKernelGGL((k_conv_gemm_h2<2, 3>), dim3(g.N / 96, (g.M + 255) / 256, ks), dim3(256), 0, st, g, wh, wl);
-        if (ks > 1) {
-            const size_t n = (size_t)g.M * g.N;
-            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
-        }
-        return;
-    }
     static const int xcd_on = [] { const char* e = std::getenv("Q3_CODEC_XCD"); return e ? atoi(e) : 1; }();
     g.xcd_swizzle = xcd_on;
     static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
-        static const int h3_nt6 = [] { const char* e = std::getenv("Q3_CODEC_H3_NT6"); return e ? atoi(e) : 0; }(); // workgroups from which N % 192 == 0 uses 192-column tiles
-        if (h3_nt6 > 0 && (g.N / 96) * ((g.M + 255) / 256) >= h3_nt6) // "NT6" knob reused: workgroups from which the 256-row tile is used
-            hipLaunchKernelGGL((k_conv_gemm_h3<2, 3, 32>), dim3(g.N / 96, (g.M + 255) / 256, 1), dim3(256), 0, st, g, wh, wl);
-        else {
-            static const int h3_bk64 = [] { const char* e = std::getenv("Q3_CODEC_H3_BK64"); return e ? atoi(e) : 0; }(); // K from which the 64-deep K tile is used (0 = never)
-            if (h3_bk64 > 0 && g.cin % 64 == 0 && g.K >= h3_bk64) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 64>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
-            else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
-        }
+        hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
         return;
     }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
@@ -1130,7 +845,6 @@ struct CodecDecoder::Impl {
 };
 
 CodecDecoder::CodecDecoder(const std::string& path, int n_streams, int max_frames, int n_lanes, int max_group) : impl_(new Impl()) {
-    init_codec_kernel_attributes();
     Impl& m = *impl_;
     if (const char* e = std::getenv("Q3_CODEC_PRESPLIT")) m.presplit = !(e[0] == '0');
     if (g_codec_f32) m.presplit = false; // the f32-only A/B mode keeps full f32 operands

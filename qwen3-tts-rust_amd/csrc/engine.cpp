@@ -32,9 +32,6 @@ Engine::Engine(const EngineParams& p) : p_(p) {
     B_ = B;
     talker_.reset(new Transformer(dir + "/qwen3_tts_talker.gguf", Q3_TALKER_NCTX, std::max(256, B)));
     predictor_.reset(new Transformer(dir + "/qwen3_tts_predictor.gguf", Q3_PRED_NCTX, 2 * B));
-    // experiment switch: fold the predictor's attention into its o-proj launch (k_oproj_attn).  Measured on MI355X: 3.23 vs
-    // 3.07 ms/frame -- the single-wave attention chain costs more than the launch it removes, so it stays off by default.
-    if (const char* e = std::getenv("Q3_FOLD_ATTN")) predictor_->set_short_context(e[0] == '1');
     if (const char* e = std::getenv("Q3_PRED_FUSED_MAX")) predictor_->set_fused_max_tokens(atoi(e)); // experiment knob
     // The predictor never holds more than 17 positions per sequence: wide steps use the single-wave attention kernel (one wave per
     // token and kv head, no workgroup barrier).  At one sequence it loses to k_attention_fused (3.24 vs 3.06 ms/frame: the serial PV

@@ -63,9 +63,8 @@ struct KvCache {           // paged f16 KV cache (pages of 64 positions)
 // out[(sseg*ntok + tok)*out_stride + r] = super-segment partial of row (row0+r) . x[tok]      (spec S3)
 // batched steps: gate/up GEMM on the matrix cores with the SwiGLU + quantisation epilogue; false = shape not supported (caller falls back)
 bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* xq, const uint16_t* xd, int8_t* aq, uint16_t* ad, int ntok);
-struct NormTail;   // norm_tail.h: the consumer's residual + RMSNorm + quantisation, run by the last workgroups of the GEMM (*tail_fused says whether it was)
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
-                    float* out, int out_stride, int ntok, int lpr_hint = 0, const NormTail* tail = nullptr, bool* tail_fused = nullptr);
+                    float* out, int out_stride, int ntok, int lpr_hint = 0);
 
 // h = h_in (+ sum of nparts partial slabs, in order); optional store h_out; xn = rmsnorm(h)*g (spec S4);
 // quantise to int8 blocks (spec S2).  h_in may be indirect: row idx[tok] of a table (idx != nullptr).
@@ -151,9 +150,6 @@ void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, in
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
                             const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, int8_t* aq, uint16_t* ad, int ntok,
                             float* att = nullptr /*optional f32 rows [ntok][n_head*128]*/);
-void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
-                       const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
-                       const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok);
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk /*[n_out/16][n_in][16]*/, const float* b,
                         int n_in, int n_out, float* out, int out_stride, int ntok);
 void launch_feedback_keys(hipStream_t st, const float* const* tables, const int64_t* table_rows, const q3_u64* keys, int key_stride,

@@ -13,7 +13,6 @@
 #include "../../include/q3tts_spec.h"
 #include "kdev.h"
 #include "wslice.h"
-#include "norm_tail.h"
 
 namespace q3 {
 
@@ -90,37 +89,11 @@ __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __rest
 // v_pk_add_f32 per pair instead of two v_cvt_f32_i32 -- but the lost occupancy costs more than the 8 VALU instructions per block it saves
 // (AR step 5.64 vs 5.54 ms, prefill 52.7 vs 45.8 ms); squeezed into 128 VGPRs the constant tile spills (7.75 ms).
 #define Q3_GEMM_Q8_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
-template <bool GU, int SM>
-__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad, NormTail tail);
-template <bool GU, int ABL = 0>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
 template <bool GU>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_gemm_q8_wave(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out,
-               int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
-static int wave_form_min();
-// Which form serves a launch.  Measured on MI355X (scripts/ubench_gemm.hip, profiles/r02_ubench_gemm.txt): at 64 tokens the first form (two
-// workgroups per CU, phases of different workgroups overlap) and the second (one pass, no conversions, 2 waves per SIMD) tie per launch
-// (talker gate/up 17.6 vs 18.0 us) and the first wins the 64-slot step (7.43 vs 7.74 ms, 618 vs 593 audio-s/s) and the 256-slot run (920 vs
-// 846 audio-s/s), so the first form serves every launch and the second is opt-in (Q3_GEMM_V2=1).  The wave-per-tile form needs >= ~1500
-// waves and is bound by activation re-reads through L2 (as many activation bytes as weight bytes per tile); opt-in too (Q3_GEMM_WAVE_MIN).
-static bool gemm_v1(int ntok) {
-    static const int mode = [] { const char* a = std::getenv("Q3_GEMM_V1"); const char* b = std::getenv("Q3_GEMM_V2"); return (a && a[0] == '1') ? 1 : (b && b[0] == '1') ? 2 : 0; }();
-    return mode != 2;
-}
-// token tiles per launch dimension z of the second form: one workgroup (8 waves) per CU at 2 waves per SIMD, so aim at >= 2 workgroups per CU
-static int mfma2_ztiles(int rowgroups, int nsseg, int ntok) {
-    const int ntiles = (ntok + 31) / 32;
-    static const int target = [] { const char* e = std::getenv("Q3_MFMA2_WGS"); return e ? atoi(e) : 512; }();
-    int z = (target + rowgroups * nsseg - 1) / (rowgroups * nsseg);
-    return z < 1 ? 1 : (z > ntiles ? ntiles : z);
-}
-__global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                              float* __restrict__ out, int out_stride, int ntok);
-template <int TYPE, int WPE> // WPE = waves per SIMD the register budget is cut for: 4 = 128 VGPRs (spills 200 B per lane, 2 workgroups per CU), 2 = 256 VGPRs (no spill, 1 per CU)
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+template <int TYPE> // register budget cut for 2 waves per SIMD = 256 VGPRs (no spill, 1 workgroup per CU; the 128-VGPR build spilled 200 B per lane in its K loop)
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x, int x_stride, float* __restrict__ out, int out_stride, int ntok);
 void init_fused_kernel_attributes();
 // dynamic-LDS opt-ins (per device): done once at engine construction so that no attribute call happens inside a stream capture
@@ -131,22 +104,17 @@ void init_kernel_attributes() {
     if (dev < 0 || dev > 63 || done[dev]) return;
     Q3_HIP(hipFuncSetAttribute((const void*)k_gemm_q8_tok, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024));
     constexpr int lds = Q3_SSEG_SEGS * 64 * 33 * (int)sizeof(float); // k_gemm_float_mfma: [8 segments][64 rows][FM_PAD]
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16, 4>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F32>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_F16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    Q3_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(&k_gemm_float_mfma<Q3_T_BF16>), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     init_fused_kernel_attributes();
     done[dev] = true;
 }
-static bool kq_wpe4() { static const bool on = [] { const char* e = std::getenv("Q3_KQ_MFMA_WPE4"); return e ? e[0] == '1' : false; }(); return on; } // measured: the 128-VGPR build of the Q5_K body (36-112 B of scratch, two workgroups per CU) is SLOWER: C3 on Q5_K_M 455 vs 487 audio-s/s
 static bool kq_mfma() { static const bool on = [] { const char* e = std::getenv("Q3_KQ_MFMA"); return e ? e[0] == '1' : true; }(); return on; } // 0: K-quant batches through the z-tiled GEMV
-template <bool GU, int TS, int WPE>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <bool GU, int TS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
-static int q8_scale_mfma() { static const int m = [] { const char* e = std::getenv("Q3_Q8_SCALE_MFMA"); return e ? atoi(e) : 1; }(); return m; } // 0: scales through LDS, 1: scale tiles from the f32 matrix pipe
 // token tiles per launch dimension z: as few as keep >= 256 workgroups in flight (z = 1 streams the weights exactly once)
 static int mfma_ztiles(int rowgroups, int nsseg, int ntok) {
     const int ntiles = (ntok + 31) / 32;
@@ -238,16 +206,12 @@ static void gemv_launch_mt(hipStream_t st, const Q8Mat& w, int row0, int nrows, 
     else gemv_launch<LPR, 8>(st, w, row0, nrows, xq, xd, out, out_stride, ntok);
 }
 void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd,
-                    float* out, int out_stride, int ntok, int lpr_hint, const NormTail* tail, bool* tail_fused) {
-    if (tail_fused) *tail_fused = false;
+                    float* out, int out_stride, int ntok, int lpr_hint) {
     const int nsseg = ((w.K >> 8) + 7) / 8;
     if (w.rg_type && ntok >= 16 && !lpr_hint && kq_mfma()) { // K-quant rows on the matrix cores (k_gemm_kq_mfma)
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
-        // (opt-in Q3_KQ_MFMA_WPE4=1: the Q5_K / Q8_0 bodies squeezed into 128 VGPRs for two workgroups per CU -- measured slower, see kq_wpe4)
-        Q3_TS_SWITCH(w, { if (kq_wpe4() && (TS == Q3_T_Q5_K || TS == Q3_T_Q8_0))
-                              hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS, 4>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
-                          else hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS, 2>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr); });
+        Q3_TS_SWITCH(w, hipLaunchKernelGGL((k_gemm_kq_mfma<false, TS>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr));
         return;
     }
     if (w.rg_type) { // mixed K-quant matrix: one kernel handles every type; tokens beyond 8 go to z tiles
@@ -266,22 +230,8 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
-        if (!gemm_v1(ntok) && (long)rgs * nsseg * ((ntok + 31) / 32) >= wave_form_min()) {
-            hipLaunchKernelGGL((k_gemm_q8_wave<false>), dim3((rgs + 3) / 4, nsseg, (ntok + 31) / 32), dim3(256), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0,
-                               (int8_t*)nullptr, (uint16_t*)nullptr);
-            return;
-        }
-        if (!gemm_v1(ntok)) {
-            hipLaunchKernelGGL((k_gemm_q8_mfma2<false>), dim3(rgs, nsseg, mfma2_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out,
-                               out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
-            return;
-        }
-        NormTail nt{};
-        if (tail && tail->counters && 64 * nw >= 64 * (tail->d >> 8) && (tail->d & 255) == 0 && tail->d <= 2048 && !tail->a.idx_keys) { nt = *tail; if (tail_fused) *tail_fused = true; }
-#define Q3_MF(SMV) hipLaunchKernelGGL((k_gemm_q8_mfma<false, SMV>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, \
-                                     out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr, nt)
-        if (q8_scale_mfma()) Q3_MF(1); else Q3_MF(0);
-#undef Q3_MF
+        hipLaunchKernelGGL((k_gemm_q8_mfma<false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0,
+                           (int8_t*)nullptr, (uint16_t*)nullptr);
         return;
     }
     if (ntok > 8 && !lpr_hint) {
@@ -311,23 +261,12 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
         if (!kq_mfma() || wgu.nparts != 1) return false;
         int z = mfma_ztiles(rgs, 1, ntok);
         if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-        Q3_TS_SWITCH(wgu, { if (kq_wpe4() && (TS == Q3_T_Q5_K || TS == Q3_T_Q8_0)) hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS, 4>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
-                            else hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS, 2>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad); });
-        return true;
-    }
-    if (!gemm_v1(ntok) && (long)rgs * ntiles >= wave_form_min()) {
-        hipLaunchKernelGGL((k_gemm_q8_wave<true>), dim3((rgs + 3) / 4, 1, ntiles), dim3(256), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
-        return true;
-    }
-    if (!gemm_v1(ntok)) {
-        hipLaunchKernelGGL((k_gemm_q8_mfma2<true>), dim3(rgs, 1, mfma2_ztiles(rgs, 1, ntok)), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+        Q3_TS_SWITCH(wgu, hipLaunchKernelGGL((k_gemm_kq_mfma<true, TS>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad));
         return true;
     }
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-#define Q3_MG(SMV) hipLaunchKernelGGL((k_gemm_q8_mfma<true, SMV>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad, NormTail{})
-    if (q8_scale_mfma()) Q3_MG(1); else Q3_MG(0);
-#undef Q3_MG
+    hipLaunchKernelGGL((k_gemm_q8_mfma<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
     return true;
 }
 
@@ -421,16 +360,14 @@ typedef float f32x32q __attribute__((ext_vector_type(32)));
 // GU = gate/up form for K <= 2048: pass 0 runs the 32 gate rows over the workgroup's tiles and parks the sums in LDS, pass 1
 // runs the 32 matching up rows and finishes with SwiGLU + int8 quantisation of the 32-row block (spec S8, S2); the f32
 // gate/up matrix never reaches memory.  A GU workgroup handles at most 4 token tiles (launcher picks gridDim.z accordingly).
-// SM = the per-block scales d_x[token] * d_w[row] come from the f32 matrix pipe: both factors are f16 values, so the product is exact in
+// The per-block scales d_x[token] * d_w[row] come from the f32 matrix pipe: both factors are f16 values, so the product is exact in
 // f32, and it is an outer product -- one v_mfma_f32_32x32x1_2b_f32 (K = 1: one exact product per output, C = 0) delivers the scale tiles of
-// two blocks in the C layout of the int8 MFMA.  That takes the 8 v_pk_mul_f32 + 4 ds_read_b128 per block and the LDS staging round (with
-// its barrier) off the VALU-bound chain; same bits (the product was exact before, too).
-template <bool GU, int SM> // SM: 0 = scales through LDS, 1 = one f32 MFMA per block pair
+// two blocks in the C layout of the int8 MFMA (no LDS staging of scales, no v_pk_mul on the VALU-bound chain).
+template <bool GU>
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq,
                                                       const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
-                                                      int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad, NormTail tail) {
+                                                      int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ __attribute__((aligned(16))) float red[8][32][33];
-    __shared__ __attribute__((aligned(16))) float sc_s[8][2][8][16]; // [wave][lane half][block][accumulator reg]: activation scales, widened to f32 once
     __shared__ float gate_s[GU ? 4 : 1][GU ? 1024 : 1];
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int r = lane & 31, half = lane >> 5;
@@ -458,21 +395,11 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 #pragma unroll 1
         for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z, lt++) {
             const int tok0 = tt * 32;
-            if (!SM && active) { // stage this wave's activation scales: token (lane & 31), blocks 4*(lane >> 5) .. +3
-                int t = tok0 + r;
-                if (t > ntok - 1) t = ntok - 1;
-                const uint2 v = *reinterpret_cast<const uint2*>(xd + (size_t)t * nb + seg * 8 + 4 * half);
-                const int th = (r >> 2) & 1, tg = (r & 3) + 4 * (r >> 3); // token r sits in C row (reg tg, lane half th)
-                sc_s[wave][th][4 * half + 0][tg] = h2f(v.x & 0xFFFFu); sc_s[wave][th][4 * half + 1][tg] = h2f(v.x >> 16);
-                sc_s[wave][th][4 * half + 2][tg] = h2f(v.y & 0xFFFFu); sc_s[wave][th][4 * half + 3][tg] = h2f(v.y >> 16);
-            }
-            if (!SM) __syncthreads();
             if (active) {
                 int atok = tok0 + r; // A operand: this lane feeds token (lane & 31)
                 if (atok > ntok - 1) atok = ntok - 1;
                 const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
-                uint4 dxa = make_uint4(0, 0, 0, 0);
-                if (SM) dxa = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8); // this token's 8 block scales
+                const uint4 dxa = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8); // this token's 8 block scales
                 // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
                 // the scale chain runs on register pairs so it can issue as v_pk_mul_f32 / v_pk_fma_f32 (IEEE per component, same bits)
                 f32x2v acc2[8];
@@ -481,7 +408,7 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
                 // activation blocks fetched at a time: 2 in the gate/up form keeps the kernel inside 128 VGPRs without spilling.  (A per-block 16-register scale
                 // tile -- v_mfma_f32_32x32x2_f32 with the second k fed zeros -- frees registers for 4 or 8 blocks in flight; built and measured in round 2: C3 612 / 548
                 // vs 616 audio-s/s, the fetch latency is already hidden by the SIMD's other waves, so it was removed again.)
-                constexpr int AB = (SM && GU) ? 2 : 4;
+                constexpr int AB = GU ? 2 : 4;
 #pragma unroll
                 for (int ih = 0; ih < 8 / AB; ih++) {
                     i32x4v av[AB];
@@ -491,7 +418,7 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 #pragma unroll
                     for (int i4 = 0; i4 < AB; i4++) {
                         const int i = AB * ih + i4;
-                        if (SM && (i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
+                        if ((i4 & 1) == 0) { // scale tiles of blocks i (lanes 0..31 feed it) and i + 1 (lanes 32..63)
 #pragma unroll
                             for (int g = 0; g < 32; g++) D[g] = 0.0f;
                             const uint32_t ex = half ? half_of(dxa, i + 1) : half_of(dxa, i), ew = half ? half_of(dwv, i + 1) : half_of(dwv, i);
@@ -501,18 +428,10 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 #pragma unroll
                         for (int g = 0; g < 16; g++) c[g] = 0;
                         c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i4], wv[i], c, 0, 0, 0);
-                        const float dwf = h2f(half_of(dwv, i));
-                        const f32x2v dw2 = f32x2v{dwf, dwf};
 #pragma unroll
                         for (int g4 = 0; g4 < 4; g4++) {
-                            f32x2v sc_a, sc_b;
-                            if (SM) {
-                                const int o = 16 * (i4 & 1) + 4 * g4;
-                                sc_a = f32x2v{D[o], D[o + 1]}; sc_b = f32x2v{D[o + 2], D[o + 3]};
-                            } else {
-                                const float4 sx = *reinterpret_cast<const float4*>(&sc_s[wave][half][i][4 * g4]);
-                                sc_a = dw2 * f32x2v{sx.x, sx.y}; sc_b = dw2 * f32x2v{sx.z, sx.w};
-                            }
+                            const int o = 16 * (i4 & 1) + 4 * g4;
+                            const f32x2v sc_a = f32x2v{D[o], D[o + 1]}, sc_b = f32x2v{D[o + 2], D[o + 3]};
                             const f32x2v ca = f32x2v{(float)c[4 * g4], (float)c[4 * g4 + 1]}, cb = f32x2v{(float)c[4 * g4 + 2], (float)c[4 * g4 + 3]};
                             acc2[2 * g4] = __builtin_elementwise_fma(ca, sc_a, acc2[2 * g4]);
                             acc2[2 * g4 + 1] = __builtin_elementwise_fma(cb, sc_b, acc2[2 * g4 + 1]);
@@ -547,7 +466,6 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
             __syncthreads(); // red / sc_s are rewritten by the next tile
         }
     }
-    if (!GU) norm_tail(tail, ntok, reinterpret_cast<unsigned char*>(&red[0][0][0])); // the consumer's residual + RMSNorm + quant (norm_tail.h)
 }
 
 // -----------------------------------------------------------------------------------------------------
@@ -562,8 +480,8 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
 // product with 1.0 lays the activation scales of two blocks out in the C layout.  Built for 2 waves per SIMD (the extra accumulators do not fit 128 VGPRs).
 // Before this kernel the batched path of a Q5_K_M file swept the weights once per 8 tokens (k_gemv_kq z tiles): C3 247 audio-s/s against 620 on Q8_0.
 // -----------------------------------------------------------------------------------------------------
-template <bool GU, int TS, int WPE>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE)))
+template <bool GU, int TS>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
 k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out, int out_stride,
                int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
     __shared__ float red[8][32][33];
@@ -681,296 +599,6 @@ k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
     });
 }
 
-// -----------------------------------------------------------------------------------------------------
-// Second form of the batched int8 GEMM (default; Q3_GEMM_V1=1 restores the kernel above for A/B runs).  Same spec arithmetic, same
-// launch geometry and LDS segment combine; what changed is everything that kept the first form far from both of its roofs:
-//   * float(idot) without v_cvt_f32_i32: the int8 MFMA accumulates on top of the bit pattern of 1/(2 pi) = 0x3E22F983 -- an INLINE constant
-//     of the ISA, so the C operand costs no registers -- whose binade [2^-3, 2^-2) has room for -2 292 099 ... +6 096 508 mantissa steps
-//     (|idot| <= 128 * 127 * 32 = 520 192).  The accumulator, read as f32, is then c0 + idot * 2^-26 exactly; c0 is subtracted (exact: the
-//     result has <= 20 significant bits) and the factor 2^26 is folded into the scale tile (a power of two: exact).  fma(idot * 2^-26,
-//     2^26 * dw * dx, acc) rounds the same real number idot * dw * dx + acc once, so the bits are those of the spec's fma.  Per 32 x 32 tile
-//     and block: 8 v_pk_add_f32 + 8 v_pk_fma_f32 instead of 16 v_cvt + 8 v_pk_fma.
-//   * gate/up form: both weight tiles are resident (64 VGPRs), so a token tile is loaded once and both products finish in one pass --
-//     no second weight-load latency behind the first pass, no gate sums parked in LDS.
-//   * all 8 activation blocks of a token tile are fetched at once and the NEXT tile's blocks before the current tile is computed; the
-//     kernel is built for 2 waves per SIMD (256 VGPRs) -- latency is hidden by what a wave has in flight, not by more waves.
-// -----------------------------------------------------------------------------------------------------
-#define Q3_GEMM2_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
-// ABL: ablation switches for scripts/ubench_gemm.hip only (1 = no matrix/vector work, 2 = no activation loads, 4 = no weight loads,
-// 8 = no LDS combine / epilogue stores); production code instantiates ABL = 0
-template <bool GU, int ABL>
-__global__ void Q3_GEMM2_BUDGET k_gemm_q8_mfma2(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
-                                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq,
-                                                uint16_t* __restrict__ ad) {
-    constexpr int NM = GU ? 2 : 1;
-    __shared__ float red[NM][8][32][32]; // [matrix][segment][token][row]: lanes of a half write / read consecutive words
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, half = lane >> 5;
-    const int nseg = w.K >> 8, nb = w.K >> 5;
-    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
-    int nsg = nseg - sseg * 8;
-    if (nsg > 8) nsg = 8;
-    const bool active = seg < nseg; // wave-uniform
-    const int ntiles = (ntok + 31) >> 5;
-    constexpr int MAGIC = 0x3E22F983;
-    const float c0 = __int_as_float(MAGIC);
-    const f32x2v negc0 = f32x2v{-c0, -c0};
-    // Issue order = arrival order the compute loop wants: the (L2-resident) activations and the scale vectors first, then the weight blocks in
-    // the order the block pairs consume them, gate and up interleaved -- the first matrix instructions start while later weight blocks are
-    // still streaming in (the compiler places counted s_waitcnt vmcnt before each first use), instead of after the last load has landed.
-    i32x4v av[8];
-    uint4 dxa = make_uint4(0, 0, 0, 0);
-    auto load_x = [&](int tt, i32x4v* a, uint4& dx) {
-        int atok = tt * 32 + r;
-        if (atok > ntok - 1) atok = ntok - 1;
-        const int8_t* xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
-        dx = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8);
-#pragma unroll
-        for (int i = 0; i < 8; i++) a[i] = (ABL & 2) ? i32x4v{lane, i, tt, 2} : *reinterpret_cast<const i32x4v*>(xp + i * 32);
-    };
-    i32x4v wv[NM][8];
-    uint4 dwv[NM];
-    if (active) {
-        const uint8_t* base[NM];
-#pragma unroll
-        for (int q = 0; q < NM; q++) {
-            int row = row0 + blockIdx.x * 32 + r + q * ff;
-            if (row > w.Npad - 1) row = w.Npad - 1;
-            const int rg = row >> 5, r32 = row & 31;
-            base[q] = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
-            dwv[q] = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
-        }
-        load_x(blockIdx.z, av, dxa);
-#pragma unroll
-        for (int i = 0; i < 8; i++)
-#pragma unroll
-            for (int q = 0; q < NM; q++) wv[q][i] = (ABL & 4) ? i32x4v{lane, i, q, 1} : *reinterpret_cast<const i32x4v*>(base[q] + (size_t)i * 1024);
-    }
-    // B operand of the scale outer product: lanes 0..31 feed block 2p, lanes 32..63 block 2p + 1, with the 2^26 of the magic offset folded in
-    float ew[NM][4];
-#pragma unroll
-    for (int q = 0; q < NM; q++)
-#pragma unroll
-        for (int p = 0; p < 4; p++) ew[q][p] = active ? h2f(half ? half_of(dwv[q], 2 * p + 1) : half_of(dwv[q], 2 * p)) * 67108864.0f : 0.0f;
-#pragma unroll 1
-    for (int tt = blockIdx.z; tt < ntiles; tt += gridDim.z) {
-        const int tok0 = tt * 32, tn = tt + gridDim.z;
-        i32x4v avn[8];
-        uint4 dxn = make_uint4(0, 0, 0, 0);
-        if (active && tn < ntiles) load_x(tn, avn, dxn); // next tile in flight while this one is computed
-        if (active) {
-            // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
-            f32x2v acc[NM][8];
-#pragma unroll
-            for (int q = 0; q < NM; q++)
-#pragma unroll
-                for (int g = 0; g < 8; g++) acc[q][g] = f32x2v{0.0f, 0.0f};
-            if (ABL & 1) {
-#pragma unroll
-                for (int q = 0; q < NM; q++)
-#pragma unroll
-                    for (int g = 0; g < 8; g++) acc[q][g] = f32x2v{__int_as_float(av[g][q] ^ wv[q][g][1]), __int_as_float(av[g][2] ^ wv[q][g][3])};
-            } else
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const float ex = h2f(half ? half_of(dxa, 2 * p + 1) : half_of(dxa, 2 * p));
-#pragma unroll
-                for (int q = 0; q < NM; q++) {
-                    f32x32q D;
-#pragma unroll
-                    for (int g = 0; g < 32; g++) D[g] = 0.0f;
-                    D = __builtin_amdgcn_mfma_f32_32x32x1f32(ex, ew[q][p], D, 0, 0, 0); // exact: f16 x f16 x 2^26
-#pragma unroll
-                    for (int i2 = 0; i2 < 2; i2++) {
-                        const int i = 2 * p + i2;
-                        i32x16 c;
-#pragma unroll
-                        for (int g = 0; g < 16; g++) c[g] = MAGIC;
-                        c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[q][i], c, 0, 0, 0);
-#pragma unroll
-                        for (int g4 = 0; g4 < 4; g4++) {
-                            const int o = 16 * i2 + 4 * g4;
-                            const f32x2v ca = f32x2v{__int_as_float(c[4 * g4]), __int_as_float(c[4 * g4 + 1])} + negc0;
-                            const f32x2v cb = f32x2v{__int_as_float(c[4 * g4 + 2]), __int_as_float(c[4 * g4 + 3])} + negc0;
-                            acc[q][2 * g4] = __builtin_elementwise_fma(ca, f32x2v{D[o], D[o + 1]}, acc[q][2 * g4]);
-                            acc[q][2 * g4 + 1] = __builtin_elementwise_fma(cb, f32x2v{D[o + 2], D[o + 3]}, acc[q][2 * g4 + 1]);
-                        }
-                    }
-                }
-            }
-            if (ABL & 8) { // keep the results alive with one conditional store
-                float sum = 0.0f;
-#pragma unroll
-                for (int q = 0; q < NM; q++)
-#pragma unroll
-                    for (int g = 0; g < 16; g++) sum += acc[q][g >> 1][g & 1];
-                if (sum == 1.2345f) red[0][0][0][0] = sum;
-            } else
-#pragma unroll
-            for (int q = 0; q < NM; q++)
-#pragma unroll
-                for (int g = 0; g < 16; g++) red[q][wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[q][g >> 1][g & 1];
-        }
-        __syncthreads();
-        if (!(ABL & 8))
-        for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
-            const int m = t >> 5, rr = t & 31, tok = tok0 + m;
-            float S = red[0][0][m][rr];
-            for (int s2 = 1; s2 < nsg; s2++) S = S + red[0][s2][m][rr];
-            if (!GU) {
-                const int orow = blockIdx.x * 32 + rr;
-                if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
-            } else {
-                float U = red[NM - 1][0][m][rr];
-                for (int s2 = 1; s2 < nsg; s2++) U = U + red[NM - 1][s2][m][rr];
-                const float y = q3_swiglu(S, U);
-                float amax = q3_fabsf(y);
-                amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
-                amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
-                const float dd = amax / 127.0f;
-                const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
-                if (tok < ntok) {
-                    aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
-                    if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
-                }
-            }
-        }
-        __syncthreads(); // red is rewritten by the next tile
-        if (tn < ntiles) {
-#pragma unroll
-            for (int i = 0; i < 8; i++) av[i] = avn[i];
-            dxa = dxn;
-        }
-    }
-}
-
-// -----------------------------------------------------------------------------------------------------
-// Third form, for launches with enough (row group, token tile) pairs to fill the chip on their own (talker gate/up from 64 tokens, every
-// talker matrix from ~128 tokens, prefill chunks): ONE WAVE owns a 32-row x 32-token tile over a whole super-segment.  The 8 segment
-// chains run back to back in the wave's registers and the segment sums are added in spec order in registers too, so nothing goes through
-// LDS and there is no barrier: scripts/ubench_gemm.hip shows the segment-per-wave forms above spend as long in their LDS combine + epilogue
-// (4 us of 15 for the talker gate/up at 64 tokens, 17 of 46 at 256) as in the matrix pipe.  Weights and activations of the next segment are
-// in flight while the current one is computed (2 waves per SIMD, 256 VGPRs).  Gate/up form: the wave runs the gate row group, then the
-// matching up row group, and finishes SwiGLU + the 32-row int8 quantisation in registers (the 32 rows of a block are the 32 lanes of a
-// half-wave: five DPP steps).  The 4 waves of a workgroup take 4 consecutive row groups of the SAME token tile, so the activation lines
-// they all read are fetched into the CU's L1 once.  Arithmetic per (row, token): unchanged (same chains, same order) -> same bits.
-// -----------------------------------------------------------------------------------------------------
-template <bool GU>
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2, 2)))
-k_gemm_q8_wave(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd, float* __restrict__ out,
-               int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane & 31, half = lane >> 5;
-    const int nseg = w.K >> 8, nb = w.K >> 5;
-    const int sseg = blockIdx.y, seg0 = sseg * 8;
-    int nsg = nseg - seg0;
-    if (nsg > 8) nsg = 8;
-    const int rgi = blockIdx.x * 4 + wave;                  // row group of this wave (of the gate half in the gate/up form)
-    if (rgi * 32 >= nrows) return;                          // wave-uniform; the kernel has no barrier
-    const int tok0 = blockIdx.z * 32;
-    constexpr int MAGIC = 0x3E22F983;
-    const float c0 = __int_as_float(MAGIC);
-    const f32x2v negc0 = f32x2v{-c0, -c0};
-    int atok = tok0 + r;
-    if (atok > ntok - 1) atok = ntok - 1;
-    const int8_t* xbase = xq + (size_t)atok * w.K + half * 16;
-    const uint16_t* dxbase = xd + (size_t)atok * nb;
-    constexpr int NM = GU ? 2 : 1;
-    f32x2v S[NM][8];
-#pragma unroll
-    for (int q = 0; q < NM; q++) {
-        int row = row0 + rgi * 32 + r + q * ff;
-        if (row > w.Npad - 1) row = w.Npad - 1;
-        const int rg = row >> 5, r32 = row & 31;
-        const uint8_t* wbase = w.qs + (size_t)rg * nb * 1024 + half * 512 + r32 * 16;
-        const uint16_t* dwbase = w.sc + ((size_t)rg * nseg * 32 + r32) * 8;
-        i32x4v wv[8], av[8];
-        uint4 dwv, dxa;
-#pragma unroll
-        for (int i = 0; i < 8; i++) wv[i] = *reinterpret_cast<const i32x4v*>(wbase + ((size_t)seg0 * 8 + i) * 1024);
-#pragma unroll
-        for (int i = 0; i < 8; i++) av[i] = *reinterpret_cast<const i32x4v*>(xbase + seg0 * 256 + i * 32);
-        dwv = *reinterpret_cast<const uint4*>(dwbase + (size_t)seg0 * 256);
-        dxa = *reinterpret_cast<const uint4*>(dxbase + seg0 * 8);
-#pragma unroll 1
-        for (int s = 0; s < nsg; s++) {
-            const bool more = s + 1 < nsg; // wave-uniform
-            const int sn = seg0 + s + (more ? 1 : 0);
-            // the next segment's operands are re-loaded block by block into the registers the matrix instructions have just consumed: every
-            // wave keeps ~16 KB in flight at all times, which across >= 1500 resident waves is what the HBM stream needs (Little's law),
-            // without a second register set
-            // (branch-free: the last segment re-loads itself -- 1/8 more L2 reads, but the body stays one basic block, which the scheduler needs
-            // to keep each pair's matrix instructions next to their vector chains instead of issuing all twelve first and spilling)
-            const uint4 dwn = *reinterpret_cast<const uint4*>(dwbase + (size_t)sn * 256);
-            const uint4 dxn = *reinterpret_cast<const uint4*>(dxbase + sn * 8);
-            f32x2v acc[8];
-#pragma unroll
-            for (int g = 0; g < 8; g++) acc[g] = f32x2v{0.0f, 0.0f};
-#pragma unroll
-            for (int p = 0; p < 4; p++) {
-                const float ex = h2f(half ? half_of(dxa, 2 * p + 1) : half_of(dxa, 2 * p));
-                const float ewp = h2f(half ? half_of(dwv, 2 * p + 1) : half_of(dwv, 2 * p)) * 67108864.0f;
-                f32x32q D;
-#pragma unroll
-                for (int g = 0; g < 32; g++) D[g] = 0.0f;
-                D = __builtin_amdgcn_mfma_f32_32x32x1f32(ex, ewp, D, 0, 0, 0);
-#pragma unroll
-                for (int i2 = 0; i2 < 2; i2++) {
-                    const int i = 2 * p + i2;
-                    i32x16 c;
-#pragma unroll
-                    for (int g = 0; g < 16; g++) c[g] = MAGIC;
-                    c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
-                    wv[i] = *reinterpret_cast<const i32x4v*>(wbase + ((size_t)sn * 8 + i) * 1024);
-                    av[i] = *reinterpret_cast<const i32x4v*>(xbase + sn * 256 + i * 32);
-#pragma unroll
-                    for (int g4 = 0; g4 < 4; g4++) {
-                        const int o = 16 * i2 + 4 * g4;
-                        const f32x2v ca = f32x2v{__int_as_float(c[4 * g4]), __int_as_float(c[4 * g4 + 1])} + negc0;
-                        const f32x2v cb = f32x2v{__int_as_float(c[4 * g4 + 2]), __int_as_float(c[4 * g4 + 3])} + negc0;
-                        acc[2 * g4] = __builtin_elementwise_fma(ca, f32x2v{D[o], D[o + 1]}, acc[2 * g4]);
-                        acc[2 * g4 + 1] = __builtin_elementwise_fma(cb, f32x2v{D[o + 2], D[o + 3]}, acc[2 * g4 + 1]);
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0); // keep the scheduler from issuing every pair's matrix instructions up front (their result tiles would not fit)
-            }
-            if (s == 0) {
-#pragma unroll
-                for (int g = 0; g < 8; g++) S[q][g] = acc[g];
-            } else {
-#pragma unroll
-                for (int g = 0; g < 8; g++) S[q][g] = S[q][g] + acc[g]; // segment sums in order (spec S3)
-            }
-            dwv = dwn; dxa = dxn;
-        }
-    }
-    // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
-    if (!GU) {
-        const int orow = rgi * 32 + r;
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int tok = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
-            if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S[0][g >> 1][g & 1];
-        }
-    } else {
-#pragma unroll
-        for (int g = 0; g < 16; g++) {
-            const int tok = tok0 + (g & 3) + 8 * (g >> 2) + 4 * half;
-            const float y = q3_swiglu(S[0][g >> 1][g & 1], S[NM - 1][g >> 1][g & 1]);
-            float amax = q3_fabsf(y);
-            amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
-            amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
-            const float dd = amax / 127.0f;
-            const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
-            if (tok < ntok) {
-                aq[(size_t)tok * ff + rgi * 32 + r] = (int8_t)(int)q3_rintf(y * id);
-                if (r == 0) ad[(size_t)tok * (ff >> 5) + rgi] = f2h(dd);
-            }
-        }
-    }
-}
-// which launches take the wave-per-tile form: enough independent (row group, token tile, super-segment) waves to occupy the SIMDs
-static int wave_form_min() { static const int v = [] { const char* e = std::getenv("Q3_GEMM_WAVE_MIN"); return e ? atoi(e) : (1 << 30); }(); return v; }
 
 // =====================================================================================================
 // residual + RMSNorm + int8 activation quantisation (spec S4, S2, S9).  One wave per token: lane l owns
@@ -1498,8 +1126,8 @@ __device__ __forceinline__ void unpack_raw(const RawChunk<TYPE>& r, float* v) {
     }
 }
 constexpr int FM_TOK = 32, FM_PAD = 33; // tokens per workgroup tile; LDS row pitch (conflict-free transposed read)
-template <int TYPE, int WPE>
-__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(WPE, WPE))) k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
+template <int TYPE>
+__global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))) k_gemm_float_mfma(const void* __restrict__ wt, int K, int tile0, int nrows, const float* __restrict__ x,
                                                          int x_stride, float* __restrict__ out, int out_stride, int ntok) {
     extern __shared__ float segsum[]; // [8 segments][64 rows][FM_PAD]
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -1769,9 +1397,7 @@ static bool gemm_float_mfma(hipStream_t st, const FMat& w, int row0, int nrows, 
         return true;
     }
     dim3 grid(xcd_grid((nrows + 63) / 64, (ntok + FM_TOK - 1) / FM_TOK));
-    static const bool wide_regs = [] { const char* e = std::getenv("Q3_FLOAT_MFMA_WPE2"); return e ? e[0] == '1' : true; }(); // default: the 256-VGPR build (no spills)
-    if (wide_regs) hipLaunchKernelGGL((k_gemm_float_mfma<TYPE, 2>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
-    else hipLaunchKernelGGL((k_gemm_float_mfma<TYPE, 4>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
+    hipLaunchKernelGGL((k_gemm_float_mfma<TYPE>), grid, dim3(512), lds, st, w.wt, w.K, row0 / 64, nrows, x, x_stride, out, out_stride, ntok);
     return true;
 }
 // fused gate/up + SwiGLU for batched steps; false = not applicable (caller runs the matmul and k_swiglu_f32)

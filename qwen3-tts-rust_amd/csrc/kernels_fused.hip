@@ -547,201 +547,6 @@ void launch_attention_fused(hipStream_t st, const float* qkv, int qkv_stride, in
 }
 
 // ===================================================================================================
-// B+C for SHORT contexts (the code predictor: <= 16 cached positions): attention folded into the o-proj GEMV.
-// The o-proj's K dimension is [head][128]; one 256-element segment = the two q heads of one kv group, so wave w of an
-// o-proj workgroup recomputes attention for kv group w (norm + RoPE + <=64 scores + softmax + PV + int8 quant, all in
-// one wave, same arithmetic as k_attention_fused) and feeds its own segment's block dots -- no extra launch and no
-// cross-wave dependency.  Every workgroup repeats the (tiny) attention; only workgroup 0 appends K/V to the cache.
-// Requires n = slot+1 <= 64, n_head*128 == 2048 handled as 8 segments, grp == 2.
-// ===================================================================================================
-template <int MT, int TS>
-__global__ void __launch_bounds__(512) k_oproj_attn(Q8Mat w, int nrows, const float* __restrict__ qkv, int qkv_stride, int n_head,
-                                                    int n_kv, const float* __restrict__ q_norm_w, const float* __restrict__ k_norm_w,
-                                                    float eps, const float* __restrict__ rope_cos, const float* __restrict__ rope_sin,
-                                                    int n_ctx, const int32_t* __restrict__ mrope_sec, TokMeta tm, KvCache kv, int layer,
-                                                    float* __restrict__ out, int out_stride, int ntok) {
-    constexpr int LPR = 8, R = 64 / LPR;
-    __shared__ float red[8][R * MT];
-    __shared__ __attribute__((aligned(16))) float q_s[8][2][128];
-    __shared__ __attribute__((aligned(16))) uint16_t kcur_s[8][128];
-    __shared__ __attribute__((aligned(16))) uint16_t vcur_s[8][128];
-    __shared__ float p_s[8][2][64];
-    __shared__ __attribute__((aligned(16))) int8_t xq_s[8][256];
-    __shared__ __attribute__((aligned(16))) uint16_t xd_s[8][8];
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int r = lane % R, q = lane / R, half = q & 1, bil = q >> 1;
-    const int nseg = w.K >> 8;
-    const int seg = wave, kvh = wave;
-    int row = blockIdx.x * R + r;
-    if (row > w.Npad - 1) row = w.Npad - 1;
-    wslice_dispatch<TS>(w, row >> 5, [&](auto tag) { // one body per weight type (wslice.h)
-        WSlice<LPR, decltype(tag)::value> ws;
-        ws.load(w, row >> 5, row & 31, seg, half, bil);
-        const float scale = 0.08838834764831845f;
-        const int jj = lane >> 4, dc = lane & 15;
-        float acc[MT];
-        for (int m = 0; m < MT; m++) {
-            acc[m] = 0.0f;
-            if (m >= ntok) continue;
-            const int tok = m;
-            const int seq = tm.seq_of(tok), slot = tm.slot_of(tok), n = slot + 1;
-            const size_t head_off = (size_t)layer * kv.layer_stride() + (size_t)kvh * 8192;
-            const int page = kv.page_of(seq, 0); // n <= 64: a single page
-            const uint16_t* Kb = kv.k + (size_t)page * kv.page_stride() + head_off;
-            const uint16_t* Vb = kv.v + (size_t)page * kv.page_stride() + head_off;
-            // ---- this token's q (2 heads), k, v for the group: norm + RoPE; lane owns the pair (l, l+64) ----
-            int32_t sec[4] = { mrope_sec[0], mrope_sec[1], mrope_sec[2], mrope_sec[3] };
-            int pp = tm.pos_of(tok, q3_mrope_stream(lane, sec));
-            if (pp < 0) pp = 0;
-            if (pp > n_ctx - 1) pp = n_ctx - 1;
-            const float cs = rope_cos[(size_t)pp * 64 + lane], sn = rope_sin[(size_t)pp * 64 + lane];
-            const float* tv = qkv + (size_t)tok * qkv_stride;
-    #pragma unroll
-            for (int which = 0; which < 3; which++) { // 0,1: q heads 2w, 2w+1 ; 2: k head
-                const float* vec = tv + (which < 2 ? (size_t)(2 * kvh + which) * 128 : (size_t)(n_head + kvh) * 128);
-                const float* wn = which < 2 ? q_norm_w : k_norm_w;
-                const float x1 = vec[lane], x2 = vec[lane + 64];
-                float p = x1 * x1;
-                p = q3_fmaf(x2, x2, p);
-                const float ss = wave_sum_bfly(p);
-                const float mean = ss / 128.0f;
-                const float sc2 = 1.0f / q3_sqrtf(mean + eps);
-                const float y1 = (x1 * sc2) * wn[lane], y2 = (x2 * sc2) * wn[lane + 64];
-                float o1, o2;
-                q3_rope_pair(y1, y2, cs, sn, &o1, &o2);
-                if (which < 2) { q_s[wave][which][lane] = o1; q_s[wave][which][lane + 64] = o2; }
-                else {
-                    const uint16_t k1 = f2h(o1), k2 = f2h(o2);
-                    kcur_s[wave][lane] = k1; kcur_s[wave][lane + 64] = k2;
-                    if (blockIdx.x == 0) {
-                        uint16_t* Kw = kv.k + (size_t)page * kv.page_stride() + head_off;
-                        Kw[((lane >> 3) * 64 + slot) * 8 + (lane & 7)] = k1;
-                        Kw[(((lane + 64) >> 3) * 64 + slot) * 8 + (lane & 7)] = k2;
-                    }
-                }
-            }
-            {
-                const float* vec = tv + (size_t)(n_head + n_kv + kvh) * 128;
-                const uint16_t v1 = f2h(vec[lane]), v2 = f2h(vec[lane + 64]);
-                vcur_s[wave][lane] = v1; vcur_s[wave][lane + 64] = v2;
-                if (blockIdx.x == 0) {
-                    uint16_t* Vw = kv.v + (size_t)page * kv.page_stride() + head_off;
-                    Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f); // lgkmcnt(0): this wave's LDS writes are done before it reads them back
-            __builtin_amdgcn_wave_barrier();
-            // ---- scores for both heads: lane = position ----
-            const bool valid = lane < n, cur = lane == slot;
-            float a0 = 0.0f, a1 = 0.0f;
-    #pragma unroll
-            for (int d8 = 0; d8 < 16; d8++) {
-                // cached K for position `lane` (garbage for lane >= n: masked; lane == slot: taken from LDS)
-                uint4 kk = *reinterpret_cast<const uint4*>(Kb + (d8 * 64 + lane) * 8);
-                if (cur) kk = *reinterpret_cast<const uint4*>(&kcur_s[wave][8 * d8]);
-                const float kf[8] = { h2f(kk.x & 0xFFFFu), h2f(kk.x >> 16), h2f(kk.y & 0xFFFFu), h2f(kk.y >> 16),
-                                      h2f(kk.z & 0xFFFFu), h2f(kk.z >> 16), h2f(kk.w & 0xFFFFu), h2f(kk.w >> 16) };
-    #pragma unroll
-                for (int e = 0; e < 8; e++) { a0 = q3_fmaf(q_s[wave][0][8 * d8 + e], kf[e], a0); a1 = q3_fmaf(q_s[wave][1][8 * d8 + e], kf[e], a1); }
-            }
-            const float s0 = valid ? a0 * scale : -INFINITY, s1 = valid ? a1 * scale : -INFINITY;
-            const float m0 = wave_max_bfly(s0), m1 = wave_max_bfly(s1);
-            const float p0 = valid ? q3_expf(s0 - m0) : 0.0f, p1 = valid ? q3_expf(s1 - m1) : 0.0f;
-            p_s[wave][0][lane] = p0; p_s[wave][1][lane] = p1;
-            const float l0 = wave_sum_bfly(p0), l1 = wave_sum_bfly(p1); // spec: a_l = p_l (+ 0 + 0 + 0), then butterfly
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            // ---- PV: the four sub-wave roles of k_attention_fused executed in turn; lane = (jj, dc) ----
-            float y[2][8];
-    #pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                float s01[8], s23[8];
-    #pragma unroll
-                for (int ww = 0; ww < 4; ww++) {
-                    float S[8];
-    #pragma unroll
-                    for (int i = 0; i < 8; i++) S[i] = 0.0f;
-    #pragma unroll
-                    for (int u = 0; u < 4; u++) {
-                        if (16 * u < n) {
-                            const int jl = 16 * u + 4 * ww + jj;
-                            const float pj = p_s[wave][hh][jl];
-                            uint4 vv = make_uint4(0, 0, 0, 0);
-                            if (jl < n) vv = (jl == slot) ? *reinterpret_cast<const uint4*>(&vcur_s[wave][dc * 8])
-                                                          : *reinterpret_cast<const uint4*>(Vb + jl * 128 + dc * 8);
-                            S[0] = q3_fmaf(pj, h2f(vv.x & 0xFFFFu), S[0]); S[1] = q3_fmaf(pj, h2f(vv.x >> 16), S[1]);
-                            S[2] = q3_fmaf(pj, h2f(vv.y & 0xFFFFu), S[2]); S[3] = q3_fmaf(pj, h2f(vv.y >> 16), S[3]);
-                            S[4] = q3_fmaf(pj, h2f(vv.z & 0xFFFFu), S[4]); S[5] = q3_fmaf(pj, h2f(vv.z >> 16), S[5]);
-                            S[6] = q3_fmaf(pj, h2f(vv.w & 0xFFFFu), S[6]); S[7] = q3_fmaf(pj, h2f(vv.w >> 16), S[7]);
-                        }
-                    }
-    #pragma unroll
-                    for (int i = 0; i < 8; i++) {
-                        const float a2 = S[i] + xor_lane<16>(S[i]);
-                        const float T = a2 + xor_lane<32>(a2);
-                        if (ww == 0) s01[i] = T; else if (ww == 1) s01[i] = s01[i] + T; else if (ww == 2) s23[i] = T; else s23[i] = s23[i] + T;
-                    }
-                }
-                const float L = hh == 0 ? l0 : l1;
-    #pragma unroll
-                for (int i = 0; i < 8; i++) y[hh][i] = (s01[i] + s23[i]) / L;
-            }
-            // ---- int8 quantisation of the 256 outputs of this kv group (8 blocks of 32 = 4 lanes x 8) ----
-    #pragma unroll
-            for (int hh = 0; hh < 2; hh++) {
-                float amax = 0.0f;
-    #pragma unroll
-                for (int i = 0; i < 8; i++) amax = fmaxf(amax, q3_fabsf(y[hh][i]));
-                amax = fmaxf(amax, xor_lane<1>(amax));
-                amax = fmaxf(amax, xor_lane<2>(amax));
-                const float dd = amax / 127.0f;
-                const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
-                if (jj == 0) {
-                    uint32_t lo = 0, hi = 0;
-    #pragma unroll
-                    for (int i = 0; i < 4; i++) {
-                        lo |= (uint32_t)((int)q3_rintf(y[hh][i] * id) & 0xFF) << (8 * i);
-                        hi |= (uint32_t)((int)q3_rintf(y[hh][i + 4] * id) & 0xFF) << (8 * i);
-                    }
-                    *reinterpret_cast<uint2*>(&xq_s[wave][hh * 128 + dc * 8]) = make_uint2(lo, hi);
-                    if ((dc & 3) == 0) xd_s[wave][hh * 4 + (dc >> 2)] = f2h(dd);
-                }
-            }
-            __builtin_amdgcn_s_waitcnt(0xc07f);
-            __builtin_amdgcn_wave_barrier();
-            // ---- this wave's o-proj segment (spec S3 block chain) ----
-            const uint4 dxv = *reinterpret_cast<const uint4*>(&xd_s[wave][0]);
-            if (m == 0) ws.finish(half); // first use: the weight words have been in flight since the top of the kernel
-            acc[m] = ws.chain(acc[m], &xq_s[wave][0], dxv, r, half, bil);
-            __builtin_amdgcn_wave_barrier();
-        }
-        if (q == 0) {
-    #pragma unroll
-            for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
-        }
-    });
-    __syncthreads();
-    for (int t = threadIdx.x; t < R * MT; t += blockDim.x) {
-        const int m = t / R, rr = t % R;
-        float S = red[0][t];
-        for (int s2 = 1; s2 < nseg; s2++) S = S + red[s2][t];
-        const int orow = blockIdx.x * R + rr;
-        if (orow < nrows && m < ntok) out[(size_t)m * out_stride + orow] = S;
-    }
-}
-void launch_oproj_attn(hipStream_t st, const Q8Mat& wo, int nrows, const float* qkv, int qkv_stride, int n_head, int n_kv,
-                       const float* q_norm_w, const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,
-                       const int32_t* mrope_sec, const TokMeta& tm, const KvCache& kv, int layer, float* out, int out_stride, int ntok) {
-    dim3 grid((nrows + 7) / 8);
-#define Q3_OA(MTV, KQV) hipLaunchKernelGGL((k_oproj_attn<MTV, TS>), grid, dim3(512), 0, st, wo, nrows, qkv, qkv_stride, n_head, n_kv, q_norm_w, k_norm_w, eps, \
-                                           rope_cos, rope_sin, n_ctx, mrope_sec, tm, kv, layer, out, out_stride, ntok)
-#define Q3_OA_MT(KQV) do { if (ntok == 1) Q3_OA(1, KQV); else if (ntok == 2) Q3_OA(2, KQV); else if (ntok <= 4) Q3_OA(4, KQV); else Q3_OA(8, KQV); } while (0)
-    Q3_TS_SWITCH(wo, Q3_OA_MT(0));
-#undef Q3_OA_MT
-#undef Q3_OA
-}
-
-// ===================================================================================================
 // Single-wave attention for sequences of at most 64 cached positions (the code predictor: <= 17): no workgroup barrier, K rows and the
 // cached V rows live in registers (both fetched before the prologue's arithmetic).  HPW = q heads per wave: 2 = one wave per (token,
 // kv head) serves both q heads of the group (fewest waves: wide steps); 1 = one wave per q head, the kv head's K/V row computed by both

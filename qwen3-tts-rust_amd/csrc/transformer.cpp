@@ -1,6 +1,5 @@
 // transformer.cpp -- see transformer.h.  (compiled by hipcc as HIP: contains the load-time repack kernel)
 #include "transformer.h"
-#include "norm_tail.h"
 #include <cstdlib>
 #include <cmath>
 
@@ -363,8 +362,6 @@ void Transformer::alloc_workspace() {
     nparts_d_ = ((ff >> 8) + 7) / 8;
     const size_t T = (size_t)max_tok_;
     scratch_.alloc(T * 32); hid_.alloc(T * d); big_logits_.alloc(T * 2176);
-    tail_counters_.alloc(2); tail_counters_.zero();
-    if (const char* e = std::getenv("Q3_NORM_TAIL")) norm_tail_ = e[0] == '1';
     if (float_mode_) { xnf_.alloc(T * d); attf_.alloc(T * dq); actf_.alloc(T * ff); }
     h_.alloc(T * d); h2_.alloc(T * d); parts_o_.alloc(T * d); parts_d_.alloc((size_t)nparts_d_ * T * d);
     qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
@@ -400,11 +397,6 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
                 launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                                       rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, qrot_.p, ntok);
                 launch_attention(st, qrot_.p, hp_.n_head, hp_.n_kv, tm, kv, l, nullptr, aq_.p, ad_.p, ntok);
-            } else if (short_ctx_ && dq == 2048 && hp_.n_head == 2 * hp_.n_kv) {
-                if (timer) timer->begin(st);
-                launch_oproj_attn(st, L.wo, d, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
-                                  n_ctx_, d_mrope_.p, tm, kv, l, parts_o_.p, d, ntok);
-                if (timer) timer->end(st, (double)L.wo.bytes());
             } else {
                 if (short_attn_min_ > 0 && ntok >= short_attn_min_ && hp_.n_head == 2 * hp_.n_kv)
                     launch_attention_short(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
@@ -413,7 +405,7 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
                 launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
                                        rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
             }
-            if (same_seq_ || !(short_ctx_ && dq == 2048 && hp_.n_head == 2 * hp_.n_kv)) gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
+            gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
             NormPro b{};
             b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.parts_slab = (size_t)ntok * d; b.h_out = h2_.p;
             b.g = L.ffn_norm; b.eps = hp_.eps;
@@ -437,21 +429,6 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         Q3_CHECK(a.idx == nullptr, "int32 row indices are not supported on the batched path");
         launch_rmsnorm_quant_wg(st, p, a.d, a.xq, a.xd, ntok);
     };
-    // GEMM with the consumer's norm as its tail (norm_tail.h); false = the norm still has to be launched
-    bool pending_done = false;
-    auto gemv_tail = [&](const Q8Mat& w, int nrows, const int8_t* xq, const uint16_t* xd, float* out, const NormArgs& a) -> bool {
-        bool fused_tail = false;
-        NormTail t{};
-        if (norm_tail_ && wgnorm && a.idx == nullptr) {
-            t.a.h_in = a.h_in; t.a.h_stride = a.h_stride; t.a.parts = a.parts; t.a.nparts = a.nparts; t.a.parts_stride = a.parts_stride;
-            t.a.parts_slab = (size_t)ntok * a.parts_stride; t.a.h_out = a.h_out; t.a.g = a.g; t.a.eps = a.eps; t.a.xn_out = a.xn_out;
-            t.d = a.d; t.xq = a.xq; t.xd = a.xd; t.counters = tail_counters_.p;
-        }
-        if (timer) timer->begin(st);
-        launch_gemv_q8(st, w, 0, nrows, xq, xd, out, nrows, ntok, 0, t.counters ? &t : nullptr, &fused_tail);
-        if (timer) timer->end(st, (double)nrows * ((double)w.K + (double)(w.K / 32) * 2.0));
-        return fused_tail;
-    };
     // NB the wg kernel forbids h_out aliasing h_in only across workgroups; here each token is one workgroup, so in-place is safe
     for (int l = 0; l < hp_.n_layer; l++) {
         const Layer& L = layers_[l];
@@ -459,14 +436,10 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         if (l == 0) { a.h_in = in.x; a.h_stride = in.x_stride; a.idx = in.idx; a.idx_keys = in.idx_keys; a.idx_stride = in.idx_stride; a.nparts = 0; }
         else { a.h_in = h_.p; a.h_stride = d; a.parts = parts_d_.p; a.nparts = nparts_d_; a.parts_stride = d; }
         a.h_out = h_.p; a.g = L.attn_norm; a.eps = hp_.eps; a.d = d; a.xq = xq_.p; a.xd = xd_.p;
-        if (!pending_done) norm(a); // (layers after the first: done by the tail of the previous layer's down-projection)
+        norm(a);
         gemv(st, L.wqkv, 0, dq + 2 * dkv, xq_.p, xd_.p, qkv_.p, dq + 2 * dkv, ntok);
-        static const bool fuse_attn = [] { const char* e = std::getenv("Q3_BATCH_FUSED_ATTN"); return e && e[0] == '1'; }();
         if (short_attn_min_ > 0 && ntok >= short_attn_min_ && !same_seq_ && hp_.n_head == 2 * hp_.n_kv)
             launch_attention_short(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
-                                   n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
-        else if (fuse_attn && fused && !same_seq_) // experiment: measured 13.4 us vs 8.0 + 4.8 us for the two-kernel form at 64 sequences
-            launch_attention_fused(st, qkv_.p, dq + 2 * dkv, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p,
                                    n_ctx_, d_mrope_.p, tm, kv, l, aq_.p, ad_.p, ntok);
         else {
             launch_qk_rope_append(st, qkv_.p, dq + 2 * dkv, nullptr, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p,
@@ -476,7 +449,8 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
         NormArgs b{};
         b.h_in = h_.p; b.h_stride = d; b.parts = parts_o_.p; b.nparts = 1; b.parts_stride = d; b.h_out = h_.p;
         b.g = L.ffn_norm; b.eps = hp_.eps; b.d = d; b.xq = xq_.p; b.xd = xd_.p;
-        if (!gemv_tail(L.wo, d, aq_.p, ad_.p, parts_o_.p, b)) norm(b);
+        gemv(st, L.wo, 0, d, aq_.p, ad_.p, parts_o_.p, d, ntok);
+        norm(b);
         bool gu_done = false;
         LaunchTimer* tg = timer_gu ? timer_gu : timer; // the talker's gate/up launch is timed on its own (bench roofline kernel)
         if (fused) {
@@ -490,13 +464,13 @@ void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMe
             gemv(st, L.wgu, 0, 2 * ff, xq_.p, xd_.p, gu_.p, 2 * ff, ntok);
             launch_swiglu_quant(st, gu_.p, ff, fq_.p, fd_.p, ntok);
         }
-        // the norm that consumes the down-projection: the next layer's attention norm, or the final norm
-        NormArgs nx{};
-        nx.h_in = h_.p; nx.h_stride = d; nx.parts = parts_d_.p; nx.nparts = nparts_d_; nx.parts_stride = d; nx.eps = hp_.eps; nx.d = d; nx.xq = xq_.p; nx.xd = xd_.p;
-        if (l + 1 < hp_.n_layer) { nx.h_out = h_.p; nx.g = layers_[l + 1].attn_norm; }
-        else { nx.h_out = nullptr; nx.g = output_norm_; nx.xn_out = hidden_out ? hidden_out : hid_.p; }
-        pending_done = gemv_tail(L.wdown, d, fq_.p, fd_.p, parts_d_.p, nx);
-        if (!pending_done && l + 1 == hp_.n_layer) norm(nx);
+        gemv(st, L.wdown, 0, d, fq_.p, fd_.p, parts_d_.p, d, ntok);
+        if (l + 1 == hp_.n_layer) { // the final norm (the next layer's attention norm consumes the down-projection otherwise)
+            NormArgs nx{};
+            nx.h_in = h_.p; nx.h_stride = d; nx.parts = parts_d_.p; nx.nparts = nparts_d_; nx.parts_stride = d; nx.eps = hp_.eps; nx.d = d; nx.xq = xq_.p; nx.xd = xd_.p;
+            nx.h_out = nullptr; nx.g = output_norm_; nx.xn_out = hidden_out ? hidden_out : hid_.p;
+            norm(nx);
+        }
     }
     Q3_LAUNCH_CHECK();
 }

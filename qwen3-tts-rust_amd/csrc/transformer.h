@@ -45,7 +45,6 @@ public:
               const ArgmaxEpi* am = nullptr, int nrows_valid = -1, float* hidden_out = nullptr);
     void set_same_seq_tokens(bool v) { same_seq_ = v; }
     // every cached context of this model stays <= 64 positions (the code predictor): fold attention into the o-proj launch
-    void set_short_context(bool v) { short_ctx_ = v; }
     // sequences never exceed 64 positions (one KV page): steps of at least `min_tok` tokens use the single-wave attention kernel
     void set_short_attention(int min_tok) { short_attn_min_ = min_tok; }
     // largest token count that still takes the 5-launch fused layer path (its GEMVs re-read the weights once per 4-8 token tile,
@@ -90,9 +89,7 @@ private:
     void alloc_workspace();
     // activations
     DevBuf<float> h_, h2_, parts_o_, parts_d_, qkv_, qrot_, gu_;
-    DevBuf<unsigned> tail_counters_; // norm_tail.h: ticket + done counters of the GEMM-tail norms (zero between launches)
-    bool norm_tail_ = false;         // Q3_NORM_TAIL=1: the batched path's norms run as GEMM tails (norm_tail.h; measured 2 x SLOWER: device-scope fences)
-    bool same_seq_ = false; bool short_ctx_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
+    bool same_seq_ = false; int short_attn_min_ = 0; int fused_max_tok_ = 8; bool last_fused_ = false; int last_ntok_ = 0; bool all_q8_ = true;
     std::map<const uint8_t*, uint8_t*>& mat_meta_ = ws_->mat_meta; std::map<const uint8_t*, uint8_t*>& mat_types_ = ws_->mat_types; std::map<const uint8_t*, uint32_t*>& mat_off_ = ws_->mat_off;
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;

@@ -1,6 +1,6 @@
 // wslice.h -- one lane's slice of a weight matrix for the GEMV family: the quants of (row, 256-segment) this lane multiplies, fetched from
 // the Q8_0 tiles or from the packed K-quant planes (kernels.h), and the block chain of spec S3 that turns them into a partial sum.
-// Shared by k_gemv_kq, k_gemv_q8_norm, k_gateup_swiglu and k_oproj_attn, so the fused decode path serves Q5_K_M files with the same
+// Shared by k_gemv_kq, k_gemv_q8_norm, and k_gateup_swiglu, so the fused decode path serves Q5_K_M files with the same
 // launches as Q8_0 files.  The weight type is a TEMPLATE parameter: a kernel reads the type of its row group from the kernel arguments (a
 // scalar) and enters the body compiled for it -- with the type as a run-time value inside one body the compiler merges the three load
 // sequences with selects on loaded data, which parks the wave on the weight stream before the norm prologue (measured: 16 -> 20 us).
