@@ -209,8 +209,11 @@ int q3tts_decoder_decode(q3tts_decoder* d, int32_t stream, const int64_t* codes,
  * (pre_conv_history, past_key_i / past_value_i, the conv_history pieces, counters) -- to checkpoint a stream, move it to another decoder
  * or device, or inspect it.  q3tts_decoder_state_entry(i) describes entry i and returns the entry count. */
 int64_t q3tts_decoder_state_floats(q3tts_decoder* d);
-int q3tts_decoder_state_export(q3tts_decoder* d, int32_t stream, float* out);
-int q3tts_decoder_state_import(q3tts_decoder* d, int32_t stream, const float* in);
+/* n_floats = the caller's buffer length; it must equal q3tts_decoder_state_floats().  _import also validates the blob's trailer (cached-position
+ * count within the attention window, frame counter finite and non-negative) before anything is committed, so a blob from another decoder
+ * configuration or a corrupted one is an error, not an out-of-range device access on the next decode. */
+int q3tts_decoder_state_export(q3tts_decoder* d, int32_t stream, float* out, int64_t n_floats);
+int q3tts_decoder_state_import(q3tts_decoder* d, int32_t stream, const float* in, int64_t n_floats);
 int32_t q3tts_decoder_state_entry(q3tts_decoder* d, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols);
 
 /* ---- mel front end (device) ---- */
@@ -278,13 +281,15 @@ int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s);                     
 int q3tts_onnx_op_executable(const char* op_type);                                       /* 1 when the executor runs the op */
 /* AudioDecoder over the executor (/root/reference/src/models/onnx.rs:322-458): the exported streaming decoder graph with its state
  * (pre_conv_history, latent_buffer, conv_history, past_key_i / past_value_i) carried on the device between chunks.  _decode returns the first
- * `valid_samples` samples of `final_wav`; *n_out receives their count (call with pcm = NULL to learn it is at most cap: the chunk is consumed
- * either way, so size pcm for the largest chunk: 1920 samples per frame for the reference's decoder). */
+ * `valid_samples` samples of `final_wav`; *n_out receives their count.  The chunk's PCM stays in the handle until the next _decode / _reset:
+ * when pcm is NULL or cap is too small the call returns 2 (state advanced, nothing lost) and q3tts_onnx_decoder_fetch copies the same chunk
+ * out again into a buffer of at least *n_out samples. */
 typedef struct q3tts_onnx_decoder q3tts_onnx_decoder;
 int q3tts_onnx_decoder_open(const char* path, int32_t device, q3tts_onnx_decoder** out);
 void q3tts_onnx_decoder_close(q3tts_onnx_decoder* d);
 int q3tts_onnx_decoder_reset(q3tts_onnx_decoder* d);
 int q3tts_onnx_decoder_decode(q3tts_onnx_decoder* d, const int64_t* codes, int32_t n_frames, int32_t is_final, float* pcm, int64_t cap, int64_t* n_out);
+int q3tts_onnx_decoder_fetch(q3tts_onnx_decoder* d, float* pcm, int64_t cap, int64_t* n_out);
 
 /* ---- kernel-level entry points used by the parity tests (host buffers in/out) ---- */
 int q3tts_op_gemv_q8(const void* w_q8_0 /* GGUF Q8_0 rows [n][k/32][34 B] */, int32_t n, int32_t k, const int8_t* xq,

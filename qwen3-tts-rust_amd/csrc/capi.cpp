@@ -298,8 +298,8 @@ int q3tts_decoder_decode(q3tts_decoder* d, int32_t stream, const int64_t* codes,
 
 // DecoderState export / import (onnx.rs:461-496)
 int64_t q3tts_decoder_state_floats(q3tts_decoder* d) { return d ? (int64_t)d->d->state_floats() : -1; }
-int q3tts_decoder_state_export(q3tts_decoder* d, int32_t stream, float* out) { Q3_API_BEGIN Q3_CHECK(d && out, "null argument"); d->d->state_export(stream, out); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
-int q3tts_decoder_state_import(q3tts_decoder* d, int32_t stream, const float* in) { Q3_API_BEGIN Q3_CHECK(d && in, "null argument"); d->d->state_import(stream, in); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
+int q3tts_decoder_state_export(q3tts_decoder* d, int32_t stream, float* out, int64_t n_floats) { Q3_API_BEGIN Q3_CHECK(d && out && n_floats >= 0, "null argument"); d->d->state_export(stream, out, (size_t)n_floats); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
+int q3tts_decoder_state_import(q3tts_decoder* d, int32_t stream, const float* in, int64_t n_floats) { Q3_API_BEGIN Q3_CHECK(d && in && n_floats >= 0, "null argument"); d->d->state_import(stream, in, (size_t)n_floats); return Q3TTS_OK; Q3_API_END(Q3TTS_ERR) }
 /* entry i of the layout: name (valid until the decoder is destroyed), offset in floats, rows x cols; returns the number of entries */
 int32_t q3tts_decoder_state_entry(q3tts_decoder* d, int32_t i, const char** name, int64_t* offset, int32_t* rows, int32_t* cols) {
     if (!d) return -1;

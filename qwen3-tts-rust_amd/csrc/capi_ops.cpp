@@ -393,7 +393,7 @@ int q3tts_onnx_session_output(q3tts_onnx_session* s, const char* name, void* dst
 int64_t q3tts_onnx_session_launches(q3tts_onnx_session* s) { return s ? (int64_t)s->s->launches() : 0; }
 int q3tts_onnx_op_executable(const char* op_type) { return op_type && q3::onnx_exec_supports(op_type) ? 1 : 0; }
 }
-struct q3tts_onnx_decoder { std::unique_ptr<q3::OnnxStreamDecoder> d; };
+struct q3tts_onnx_decoder { std::unique_ptr<q3::OnnxStreamDecoder> d; std::vector<float> last; }; // last = the most recent chunk's PCM (re-fetchable)
 extern "C" {
 int q3tts_onnx_decoder_open(const char* path, int32_t device, q3tts_onnx_decoder** out) {
     try {
@@ -406,16 +406,28 @@ int q3tts_onnx_decoder_open(const char* path, int32_t device, q3tts_onnx_decoder
 }
 void q3tts_onnx_decoder_close(q3tts_onnx_decoder* d) { delete d; }
 int q3tts_onnx_decoder_reset(q3tts_onnx_decoder* d) {
-    try { if (!d) throw q3::Error("null decoder"); d->d->reset(); return 0; } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+    try { if (!d) throw q3::Error("null decoder"); d->d->reset(); d->last.clear(); return 0; } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+static int onnx_decoder_copy_out(q3tts_onnx_decoder* d, float* pcm, int64_t cap, int64_t* n_out) {
+    *n_out = (int64_t)d->last.size();
+    if ((int64_t)d->last.size() > cap || (!pcm && !d->last.empty())) {
+        q3::set_last_error("pcm buffer too small for the chunk (" + std::to_string(d->last.size()) + " samples); the chunk is kept: call q3tts_onnx_decoder_fetch with a larger buffer");
+        return 2;
+    }
+    if (!d->last.empty()) memcpy(pcm, d->last.data(), d->last.size() * 4);
+    return 0;
 }
 int q3tts_onnx_decoder_decode(q3tts_onnx_decoder* d, const int64_t* codes, int32_t n_frames, int32_t is_final, float* pcm, int64_t cap, int64_t* n_out) {
     try {
         if (!d || !n_out) throw q3::Error("q3tts_onnx_decoder_decode: null argument");
-        const std::vector<float> v = d->d->decode(codes, n_frames, is_final != 0);
-        *n_out = (int64_t)v.size();
-        if ((int64_t)v.size() > cap || (!pcm && !v.empty())) throw q3::Error("pcm buffer too small for the chunk (" + std::to_string(v.size()) + " samples)");
-        if (!v.empty()) memcpy(pcm, v.data(), v.size() * 4);
-        return 0;
+        d->last = d->d->decode(codes, n_frames, is_final != 0); // the streaming state has advanced: the PCM stays in the handle until the next decode / reset
+        return onnx_decoder_copy_out(d, pcm, cap, n_out);
+    } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
+}
+int q3tts_onnx_decoder_fetch(q3tts_onnx_decoder* d, float* pcm, int64_t cap, int64_t* n_out) {
+    try {
+        if (!d || !n_out) throw q3::Error("q3tts_onnx_decoder_fetch: null argument");
+        return onnx_decoder_copy_out(d, pcm, cap, n_out);
     } catch (const std::exception& e) { q3::set_last_error(e.what()); return 1; }
 }
 }

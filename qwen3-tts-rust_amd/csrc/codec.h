@@ -15,8 +15,8 @@ public:
     // DecoderState (onnx.rs:461-496) out of / into the device: flat f32 blob per stream, layout = named history tensors + counters
     std::vector<CodecStateEntry> state_layout() const;
     size_t state_floats() const;
-    void state_export(int stream, float* out) const;
-    void state_import(int stream, const float* in);
+    void state_export(int stream, float* out, size_t n_floats) const; // n_floats must equal state_floats()
+    void state_import(int stream, const float* in, size_t n_floats);  // validates the blob size and its trailer before committing
     // n_lanes: independent scratch sets so that decodes of different streams can run concurrently on different HIP streams
     // max_group: how many streams one pass may decode together (decode_group_async)
     CodecDecoder(const std::string& gguf_path, int n_streams, int max_frames_per_call, int n_lanes = 1, int max_group = 1);

@@ -999,6 +999,7 @@ double CodecDecoder::flops_per_frame() const { return impl_->flops_frame; }
 void CodecDecoder::reset(int s) {
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams, "stream out of range");
+    std::lock_guard<std::mutex> cap(capture_mutex());
     for (Ext* e : m.all_ext) if (e->H) Q3_HIP(hipMemset(e->hist.p + (size_t)s * e->H * e->C, 0, (size_t)e->H * e->C * 4));
     m.kv_len[s] = 0; m.n_seen[s] = 0;
 }
@@ -1027,9 +1028,11 @@ std::vector<CodecStateEntry> CodecDecoder::state_layout() const {
     return out;
 }
 size_t CodecDecoder::state_floats() const { const auto l = state_layout(); return (size_t)l.back().offset + 2; }
-void CodecDecoder::state_export(int s, float* out) const {
+void CodecDecoder::state_export(int s, float* out, size_t n_floats) const {
     const Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams && out, "stream out of range");
+    Q3_CHECK(n_floats == state_floats(), "state_export: buffer holds " + std::to_string(n_floats) + " floats, the state has " + std::to_string(state_floats()));
+    std::lock_guard<std::mutex> cap(capture_mutex()); // synchronous copies must not overlap another thread's stream capture (engine.h)
     Q3_HIP(hipDeviceSynchronize()); // the stream's pending decodes must have landed
     size_t off = 0;
     auto one = [&](const Ext& e) { if (!e.H) return; const size_t n = (size_t)e.H * e.C; Q3_HIP(hipMemcpy(out + off, e.hist.p + (size_t)s * n, n * 4, hipMemcpyDeviceToHost)); off += n; };
@@ -1041,9 +1044,15 @@ void CodecDecoder::state_export(int s, float* out) const {
     one(m.out_ext);
     out[off] = (float)m.kv_len[s]; out[off + 1] = (float)m.n_seen[s];
 }
-void CodecDecoder::state_import(int s, const float* in) {
+void CodecDecoder::state_import(int s, const float* in, size_t n_floats) {
     Impl& m = *impl_;
     Q3_CHECK(s >= 0 && s < m.n_streams && in, "stream out of range");
+    Q3_CHECK(n_floats == state_floats(), "state_import: blob holds " + std::to_string(n_floats) + " floats, this decoder's state has " + std::to_string(state_floats()));
+    // the trailer drives device-side indexing of the KV / history buffers on the next decode: validate before anything is committed
+    const float kvf = in[n_floats - 2], seenf = in[n_floats - 1];
+    Q3_CHECK(kvf == kvf && seenf == seenf && kvf >= 0.0f && kvf <= (float)(m.window - 1) && kvf == (float)(int)kvf, "state_import: cached-position count in the blob is not an integer in [0, window)");
+    Q3_CHECK(seenf >= 0.0f && seenf < 9.0e15f && seenf == (float)(long long)seenf, "state_import: frame counter in the blob is negative or not finite");
+    std::lock_guard<std::mutex> cap(capture_mutex());
     Q3_HIP(hipDeviceSynchronize());
     size_t off = 0;
     auto one = [&](Ext& e) { if (!e.H) return; const size_t n = (size_t)e.H * e.C; Q3_HIP(hipMemcpy(e.hist.p + (size_t)s * n, in + off, n * 4, hipMemcpyHostToDevice)); off += n; };

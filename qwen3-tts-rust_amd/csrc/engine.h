@@ -67,10 +67,6 @@ struct Voice { // a registered voice: preset embedding or clone material (engine
     std::vector<float> spk_emb; std::vector<int32_t> ref_codes, ref_text_ids;
 };
 
-// Process-wide lock around frame-graph construction (stream capture).  On ROCm 7.2 a synchronous hipMemcpy / hipMalloc on ANY thread
-// while another thread captures fails ("would make the legacy stream depend on a capturing blocking stream") and invalidates the capture,
-// thread-local capture mode notwithstanding; code that must allocate or copy synchronously while engines are running takes this lock.
-std::mutex& capture_mutex();
 
 class Engine {
 public:

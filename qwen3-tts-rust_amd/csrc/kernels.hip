@@ -16,6 +16,23 @@
 
 namespace q3 {
 
+// In-kernel phase stamps for scripts/ubench_chain.hip (built with -DQ3_STAMPS; the library build compiles them to nothing): thread 0 of every
+// workgroup stores the 100 MHz s_memrealtime counter at up to 8 points of the kernel, so a phase can be placed on one time axis across workgroups.
+#ifdef Q3_STAMPS
+__device__ unsigned long long* g_q3_stamps = nullptr;
+void set_stamp_buffer(hipStream_t st, unsigned long long* p) { Q3_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q3_stamps), &p, sizeof(p), 0, hipMemcpyHostToDevice, st)); Q3_HIP(hipStreamSynchronize(st)); }
+// stamps live in SGPRs until the kernel's last instruction block (no store, no branch inside the phases); `dep` ties the read to a value the phase produced
+#define Q3_STAMP_DECL unsigned long long q3_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long q3_c0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c0_) :: "memory")
+#define Q3_STAMP(k) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]) :: "memory")
+#define Q3_STAMP_AFTER(k, dep) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]), "+v"(dep) :: "memory")
+#define Q3_STAMP_FLUSH() do { unsigned long long q3_c1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c1_) :: "memory"); q3_st_[7] = q3_c1_ - q3_c0_; if (threadIdx.x == 0 && g_q3_stamps) for (int k_ = 0; k_ < 8; k_++) g_q3_stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k_] = q3_st_[k_]; } while (0)
+#else
+#define Q3_STAMP_DECL
+#define Q3_STAMP(k) do {} while (0)
+#define Q3_STAMP_AFTER(k, dep) do {} while (0)
+#define Q3_STAMP_FLUSH() do {} while (0)
+#endif
+
 // =====================================================================================================
 // Q8_0 GEMV / skinny GEMM (spec S3).  One wave = R rows x one 256-element segment; LPR = 64/R lanes share
 // a row, each lane streaming 16 B (half a 32-block) per load.  A workgroup = up to 8 waves = one
@@ -91,6 +108,9 @@ __global__ void k_gemm_q8_tok(Q8Mat w, int row0, int nrows, const int8_t* __rest
 #define Q3_GEMM_Q8_BUDGET __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(4, 4)))
 template <bool GU>
 __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                               float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
+template <bool GU>
+__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_tile1(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
                                float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad);
 template <int TYPE> // register budget cut for 2 waves per SIMD = 256 VGPRs (no spill, 1 workgroup per CU; the 128-VGPR build spilled 200 B per lane in its K loop)
 __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2)))
@@ -230,8 +250,14 @@ void launch_gemv_q8(hipStream_t st, const Q8Mat& w, int row0, int nrows, const i
     if (ntok >= 16 && !lpr_hint) { // matrix-core path: exact int8 block dots for 32 tokens x 32 rows per MFMA
         const int nseg = w.K >> 8, nw = nseg < 8 ? nseg : 8;
         const int rgs = (nrows + 31) / 32;
-        hipLaunchKernelGGL((k_gemm_q8_mfma<false>), dim3(rgs, nsseg, mfma_ztiles(rgs, nsseg, ntok)), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0,
-                           (int8_t*)nullptr, (uint16_t*)nullptr);
+        const int z = mfma_ztiles(rgs, nsseg, ntok);
+        // one token tile per workgroup and K <= 1024 (4 waves): the latency-tuned form.  Measured in-graph at 64 tokens (profiles/r03_gemm_stamps.txt): predictor
+        // q,k,v 4.67 -> 4.46 us, head 4.50 -> 4.35; with 8 waves per workgroup (K >= 2048) its extra matrix instruction per block costs more than the
+        // combine saves (o-projection 5.3 -> 5.9 us), so those shapes stay on the resident-tile kernel
+        if (z == (ntok + 31) / 32 && nw <= 4 && !(nrows & 3) && !(out_stride & 3) && !((uintptr_t)out & 15))
+            hipLaunchKernelGGL((k_gemm_q8_tile1<false>), dim3(rgs, nsseg, z), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
+        else
+            hipLaunchKernelGGL((k_gemm_q8_mfma<false>), dim3(rgs, nsseg, z), dim3(64 * nw), 0, st, w, row0, nrows, xq, xd, out, out_stride, ntok, 0, (int8_t*)nullptr, (uint16_t*)nullptr);
         return;
     }
     if (ntok > 8 && !lpr_hint) {
@@ -266,7 +292,8 @@ bool launch_gateup_mfma(hipStream_t st, const Q8Mat& wgu, int ff, const int8_t* 
     }
     int z = mfma_ztiles(rgs, 1, ntok);
     if (z < (ntiles + 3) / 4) z = (ntiles + 3) / 4; // a workgroup parks at most 4 tiles of gate sums
-    hipLaunchKernelGGL((k_gemm_q8_mfma<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    if (z == ntiles && !((uintptr_t)aq & 3)) hipLaunchKernelGGL((k_gemm_q8_tile1<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
+    else hipLaunchKernelGGL((k_gemm_q8_mfma<true>), dim3(rgs, 1, z), dim3(wgu.K / 4), 0, st, wgu, 0, ff, xq, xd, (float*)nullptr, 0, ntok, ff, aq, ad);
     return true;
 }
 
@@ -351,6 +378,13 @@ __global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrow
 // 16 accumulator values each lane owns.  B operand = a weight tile exactly as stored (lane = half*32 + row), A operand
 // = 16 activation bytes of token (lane & 31), half (lane >> 5).  Wave = segment, workgroup = super-segment.
 // =====================================================================================================
+// Workgroup barrier for LDS hand-offs that leaves the wave's GLOBAL loads and stores in flight.  __syncthreads() on gfx950 puts s_waitcnt vmcnt(0) in
+// front of s_barrier (the target has no automatic wait), i.e. every barrier also drains the weight stream and waits for the epilogue's stores to land.
+// Here only the LDS traffic is waited for, which is all an LDS producer -> consumer hand-off needs.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+#ifndef Q3_GEMM_AB
+#define Q3_GEMM_AB 4
+#endif
 typedef int i32x16 __attribute__((ext_vector_type(16)));
 typedef int i32x4v __attribute__((ext_vector_type(4)));
 typedef float f32x2v __attribute__((ext_vector_type(2)));
@@ -378,6 +412,8 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
     const bool active = seg < nseg;
     const int ntiles = (ntok + 31) >> 5;
     constexpr int NM = GU ? 2 : 1;
+    Q3_STAMP_DECL;
+    Q3_STAMP(0);
 #pragma unroll 1
     for (int q = 0; q < NM; q++) {
         i32x4v wv[8];
@@ -408,7 +444,7 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
                 // activation blocks fetched at a time: 2 in the gate/up form keeps the kernel inside 128 VGPRs without spilling.  (A per-block 16-register scale
                 // tile -- v_mfma_f32_32x32x2_f32 with the second k fed zeros -- frees registers for 4 or 8 blocks in flight; built and measured in round 2: C3 612 / 548
                 // vs 616 audio-s/s, the fetch latency is already hidden by the SIMD's other waves, so it was removed again.)
-                constexpr int AB = GU ? 2 : 4;
+                constexpr int AB = GU ? 2 : Q3_GEMM_AB;
 #pragma unroll
                 for (int ih = 0; ih < 8 / AB; ih++) {
                     i32x4v av[AB];
@@ -438,34 +474,222 @@ __global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_mfma(Q8Mat w, int row0, int nrows, c
                         }
                     }
                 }
+                if (lt == 0) { if (q == 0) Q3_STAMP_AFTER(1, acc2[7][1]); else Q3_STAMP_AFTER(4, acc2[7][1]); }
 #pragma unroll
                 for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc2[g >> 1][g & 1];
             }
-            __syncthreads();
-            for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
-                const int m = t >> 5, rr = t & 31, tok = tok0 + m;
-                float S = red[0][m][rr];
-                for (int s2 = 1; s2 < nsg; s2++) S = S + red[s2][m][rr];
-                if (!GU) {
-                    const int orow = blockIdx.x * 32 + rr;
-                    if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
-                } else if (q == 0) gate_s[lt][t] = S; // read back by the same thread in pass 1
-                else {
-                    const float y = q3_swiglu(gate_s[lt][t], S);
-                    float amax = q3_fabsf(y);
-                    amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
-                    amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
-                    const float dd = amax / 127.0f;
-                    const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
-                    if (tok < ntok) {
-                        aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
-                        if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+            wg_barrier_lds();
+            if (lt == 0) { if (q == 0) Q3_STAMP(2); else Q3_STAMP(5); }
+            // segment sums added in spec order.  All of a round's LDS reads are issued before the first add (the rolled form -- one dependent ds_read per
+            // add, trip count nsg -- cost ~250 ns per output: in-kernel stamps, profiles/r03_gemm_stamps.txt); rows s2 >= nsg are read and ignored
+#pragma unroll 1
+            for (int t0 = threadIdx.x; t0 < 32 * 32; t0 += 2 * blockDim.x) { // two outputs per round; whole 32-lane groups share a token (blockDim % 64 == 0)
+                float v[2][8];
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int t = (t0 + u * (int)blockDim.x) & 1023, m = t >> 5, rr = t & 31;
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; s2++) v[u][s2] = red[s2][m][rr];
+                }
+#pragma unroll
+                for (int u = 0; u < 2; u++) {
+                    const int t = t0 + u * (int)blockDim.x, m = t >> 5, rr = t & 31, tok = tok0 + m;
+                    if (t >= 32 * 32) break; // (uniform over each 32-lane group)
+                    float S = v[u][0];
+#pragma unroll
+                    for (int s2 = 1; s2 < 8; s2++) S = (s2 < nsg) ? S + v[u][s2] : S;
+                    if (!GU) {
+                        const int orow = blockIdx.x * 32 + rr;
+                        if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
+                    } else if (q == 0) gate_s[lt][t] = S; // read back by the same thread in pass 1
+                    else {
+                        const float y = q3_swiglu(gate_s[lt][t], S);
+                        float amax = q3_fabsf(y);
+                        amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
+                        amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax));
+                        const float dd = amax / 127.0f;
+                        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+                        if (tok < ntok) {
+                            aq[(size_t)tok * ff + blockIdx.x * 32 + rr] = (int8_t)(int)q3_rintf(y * id);
+                            if (rr == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+                        }
                     }
                 }
             }
-            __syncthreads(); // red / sc_s are rewritten by the next tile
+            // red is rewritten by the next tile / the next pass; behind the last one the workgroup simply ends
+            if (q + 1 < NM || tt + (int)gridDim.z < ntiles) wg_barrier_lds();
+            if (q == 0 && lt == 0) Q3_STAMP(3);
         }
     }
+    Q3_STAMP(6);
+    Q3_STAMP_FLUSH();
+}
+
+
+// -----------------------------------------------------------------------------------------------------
+// One-tile form of the batched int8 GEMM: every workgroup owns exactly ONE 32-token tile (gridDim.z = token tiles; decode steps of up to ~128
+// sequences, where a launch is latency-bound, not throughput-bound).  Same arithmetic as k_gemm_q8_mfma per (row, token): same block dots, same
+// fma chain, same in-order segment sums -> same bits.  What the in-kernel stamps of that kernel showed (profiles/r03_gemm_stamps.txt) and this one removes:
+//   * activations arrived in 2 (plain) or 4 (gate/up) separately exposed L2 round trips inside the chain: here all 8 blocks of the token tile are
+//     fetched first (they are L2-resident and land before the weights), and the gate/up form fetches them ONCE for both passes.  The registers come
+//     from the scale tile: v_mfma_f32_32x32x2_f32 with the second k fed zeros lays ONE block's d_x d_w products out in the C layout (16 registers
+//     instead of the 32 of the two-block form; one more matrix instruction per block, on a pipe that is ~10 % busy at these sizes).
+//   * the up rows' weight stream started behind the gate combine and its barriers: here it is issued right behind the gate rows' matrix work and
+//     flies under them -- the barriers are LDS-only (wg_barrier_lds), they do not drain the stream.
+//   * the combine read one ds_read_b32 per add, 1 024 times per tile: here 256 threads read 8 float4 each (rows padded to 36 floats), add the four
+//     chains side by side and store 16 B (plain) / one packed dword of int8 (gate/up); blockDim / gridDim come from the arguments, not from a
+//     dispatch-packet load behind the barrier; no barrier behind the last combine.
+// Launch: grid (row groups, super-segments, token tiles), 64 * min(K / 256, 8) threads; plain form needs nrows % 4 == 0, out_stride % 4 == 0.
+// -----------------------------------------------------------------------------------------------------
+typedef float f32x16q __attribute__((ext_vector_type(16)));
+template <bool GU>
+__global__ void Q3_GEMM_Q8_BUDGET k_gemm_q8_tile1(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, const uint16_t* __restrict__ xd,
+                                                  float* __restrict__ out, int out_stride, int ntok, int ff, int8_t* __restrict__ aq, uint16_t* __restrict__ ad) {
+    __shared__ __attribute__((aligned(16))) float red[8][32][36];
+    __shared__ __attribute__((aligned(16))) float gate_s[GU ? 1024 : 4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, half = lane >> 5;
+    const int nseg = w.K >> 8, nb = w.K >> 5;
+    const int sseg = blockIdx.y, seg = sseg * 8 + wave;
+    int nsg = nseg - sseg * 8;
+    if (nsg > 8) nsg = 8;
+    const bool active = seg < nseg;
+    const int tok0 = blockIdx.z * 32;
+    Q3_STAMP_DECL;
+    Q3_STAMP(0);
+    i32x4v av[8], wv[8];
+    uint4 dxa = make_uint4(0, 0, 0, 0), dwv = dxa;
+    // A operand: this lane feeds token (lane & 31), 16 bytes of every block of the wave's segment; + the token's 8 block scales.  The gate/up form fetches
+    // them again for the up pass (L2 hits, in flight under the gate combine like the up rows' weights) instead of holding 32 registers across the
+    // combine: held, one weight block spills, and a kernel with scratch pays ~2 us per launch.  (The pointer is laundered through an empty asm: the
+    // compiler would otherwise prove the second fetch redundant and keep the registers.)
+    // NLATE: the gate/up form fetches its last 4 blocks from inside the chain (block 4 + i behind the matrix work of block i: L2 hits with four blocks
+    // of work to land under).  All 8 up front does not fit its 128 registers -- 48 of 16-aligned matrix tuples + 72 of operands + lane constants: one
+    // operand block spills, and a kernel with ANY scratch was measured ~2 us slower per launch (1, 2: still spills; 4: 126 registers, none).
+    constexpr int NLATE = GU ? 4 : 0;
+    const int8_t* xp = xq;
+    auto load_a = [&]() {
+        if (!active) return;
+        int atok = tok0 + r;
+        if (atok > ntok - 1) atok = ntok - 1;
+        xp = xq + (size_t)atok * w.K + seg * 256 + half * 16;
+        asm volatile("" : "+v"(xp) :: "memory"); // (pins the fetch: see load_w)
+#pragma unroll
+        for (int i = 0; i < 8 - NLATE; i++) av[i] = *reinterpret_cast<const i32x4v*>(xp + i * 32);
+        dxa = *reinterpret_cast<const uint4*>(xd + (size_t)atok * nb + seg * 8);
+    };
+    load_a();
+    // the wave's 32 rows x 256-element segment: gate rows / the plain rows (q = 0) or the matching up rows (q = 1); blocks [i0, i1) (+ the scales with block 0)
+    auto load_w = [&](int q, int i0, int i1) {
+        if (!active) return;
+        int row = row0 + blockIdx.x * 32 + r + q * ff;
+        if (row > w.Npad - 1) row = w.Npad - 1;
+        const int rg = row >> 5, r32 = row & 31;
+        const uint8_t* base = w.qs + ((size_t)rg * nb + (size_t)seg * 8) * 1024 + half * 512 + r32 * 16;
+        // (the weights are read-only, no-alias arguments: their loads may be scheduled anywhere, barriers included, unless the address depends on something
+        // that cannot move -- an empty volatile asm with a memory clobber pins this fetch behind the code in front of it)
+        asm volatile("" : "+v"(base) :: "memory");
+#pragma unroll
+        for (int i = 0; i < 8; i++) if (i >= i0 && i < i1) wv[i] = *reinterpret_cast<const i32x4v*>(base + (size_t)i * 1024);
+        if (i0 == 0) dwv = *reinterpret_cast<const uint4*>(w.sc + (((size_t)rg * nseg + seg) * 32 + r32) * 8);
+    };
+    auto chain = [&]() { // 8 exact int8 block dots + the spec's per-block fma chain -> this wave's segment sums in red[wave]
+        if (!active) return;
+        // C layout: column = lane & 31 (weight row), C row = (reg & 3) + 8*(reg >> 2) + 4*(lane >> 5) (token)
+        f32x2v acc2[8];
+#pragma unroll
+        for (int g = 0; g < 8; g++) acc2[g] = f32x2v{0.0f, 0.0f};
+#pragma unroll
+        for (int i = 0; i < 8; i++) {
+            f32x16q D;
+#pragma unroll
+            for (int g = 0; g < 16; g++) D[g] = 0.0f;
+            // k = 0 (lanes 0..31): d_x[token] x d_w[row], both f16 values -> exact in f32; k = 1 (lanes 32..63): 0 x 0
+            const float ex = half ? 0.0f : h2f(half_of(dxa, i)), ew = half ? 0.0f : h2f(half_of(dwv, i));
+            D = __builtin_amdgcn_mfma_f32_32x32x2f32(ex, ew, D, 0, 0, 0);
+            i32x16 c;
+#pragma unroll
+            for (int g = 0; g < 16; g++) c[g] = 0;
+            c = __builtin_amdgcn_mfma_i32_32x32x32_i8(av[i], wv[i], c, 0, 0, 0);
+            if (i < NLATE) {
+                const int8_t* xl = xp;
+                asm volatile("" : "+v"(xl), "+v"(c) :: "memory"); // behind block i's matrix instruction, not hoisted to the top
+                av[8 - NLATE + i] = *reinterpret_cast<const i32x4v*>(xl + (8 - NLATE + i) * 32);
+            }
+#pragma unroll
+            for (int g4 = 0; g4 < 4; g4++) {
+                const f32x2v sc_a = f32x2v{D[4 * g4], D[4 * g4 + 1]}, sc_b = f32x2v{D[4 * g4 + 2], D[4 * g4 + 3]};
+                const f32x2v ca = f32x2v{(float)c[4 * g4], (float)c[4 * g4 + 1]}, cb = f32x2v{(float)c[4 * g4 + 2], (float)c[4 * g4 + 3]};
+                acc2[2 * g4] = __builtin_elementwise_fma(ca, sc_a, acc2[2 * g4]);
+                acc2[2 * g4 + 1] = __builtin_elementwise_fma(cb, sc_b, acc2[2 * g4 + 1]);
+            }
+        }
+#pragma unroll
+        for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc2[g >> 1][g & 1];
+    };
+    // slot t < 256 owns token m = t >> 3 and the 4 rows c4 .. c4 + 3 of the 32-row block: segment sums added in spec order, four chains side by side.
+    // Workgroups of 256 / 512 threads (K >= 1024) give every slot its own thread; narrower ones (K = 256 .. 768) walk the slots.
+    auto seg_sums = [&](int m, int c4) -> float4 { // (rows s2 >= nsg are read and ignored; two rounds of 4 reads: all 8 at once costs the gate/up form registers it does not have)
+        float4 v[4];
+#pragma unroll
+        for (int s2 = 0; s2 < 4; s2++) v[s2] = *reinterpret_cast<const float4*>(&red[s2][m][c4]);
+        float4 S = v[0];
+#pragma unroll
+        for (int s2 = 1; s2 < 4; s2++)
+            if (s2 < nsg) { S.x = S.x + v[s2].x; S.y = S.y + v[s2].y; S.z = S.z + v[s2].z; S.w = S.w + v[s2].w; }
+        if (nsg > 4) { // wave-uniform
+            asm volatile("" ::: "memory");
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++) v[s2] = *reinterpret_cast<const float4*>(&red[4 + s2][m][c4]);
+#pragma unroll
+            for (int s2 = 0; s2 < 4; s2++)
+                if (4 + s2 < nsg) { S.x = S.x + v[s2].x; S.y = S.y + v[s2].y; S.z = S.z + v[s2].z; S.w = S.w + v[s2].w; }
+        }
+        return S;
+    };
+    const int nthr = 64 * (nseg < 8 ? nseg : 8); // = blockDim.x (from the arguments: no dispatch-packet load behind the barrier)
+    load_w(0, 0, 8);
+    chain();
+    Q3_STAMP(1);
+    // the up rows' stream (and the tile's activations again: L2 hits) starts under the gate combine
+    if (GU) { load_a(); load_w(1, 0, 8); }
+    wg_barrier_lds();
+    Q3_STAMP(2);
+    if (!GU) {
+        for (int t = threadIdx.x; t < 256; t += nthr) {
+            const int m = t >> 3, c4 = (t & 7) * 4, tok = tok0 + m;
+            const float4 S = seg_sums(m, c4);
+            const int orow = blockIdx.x * 32 + c4;
+            if (orow < nrows && tok < ntok) *reinterpret_cast<float4*>(out + ((size_t)sseg * ntok + tok) * out_stride + orow) = S;
+        }
+        Q3_STAMP(6);
+        Q3_STAMP_FLUSH();
+        return;
+    }
+    for (int t = threadIdx.x; t < 256; t += nthr) *reinterpret_cast<float4*>(&gate_s[4 * t]) = seg_sums(t >> 3, (t & 7) * 4); // read back by the same thread
+    wg_barrier_lds(); // red is rewritten by the up pass
+    Q3_STAMP(3);
+    chain();
+    Q3_STAMP(4);
+    wg_barrier_lds();
+    Q3_STAMP(5);
+    for (int t = threadIdx.x; t < 256; t += nthr) {
+        const int m = t >> 3, c4 = (t & 7) * 4, tok = tok0 + m;
+        const float4 U = seg_sums(m, c4), G = *reinterpret_cast<const float4*>(&gate_s[4 * t]);
+        const float y0 = q3_swiglu(G.x, U.x), y1 = q3_swiglu(G.y, U.y), y2 = q3_swiglu(G.z, U.z), y3 = q3_swiglu(G.w, U.w);
+        float amax = fmaxf(fmaxf(q3_fabsf(y0), q3_fabsf(y1)), fmaxf(q3_fabsf(y2), q3_fabsf(y3)));
+        amax = fmaxf(amax, xor_lane<4>(amax)); amax = fmaxf(amax, xor_lane<2>(amax)); amax = fmaxf(amax, xor_lane<1>(amax)); // the 8 lanes of the token's 32-row block
+        const float dd = amax / 127.0f;
+        const float id = (dd != 0.0f) ? (1.0f / dd) : 0.0f;
+        if (tok < ntok) {
+            const uint32_t pk = ((uint32_t)(int)q3_rintf(y0 * id) & 0xFFu) | (((uint32_t)(int)q3_rintf(y1 * id) & 0xFFu) << 8) |
+                                (((uint32_t)(int)q3_rintf(y2 * id) & 0xFFu) << 16) | (((uint32_t)(int)q3_rintf(y3 * id) & 0xFFu) << 24);
+            *reinterpret_cast<uint32_t*>(aq + (size_t)tok * ff + blockIdx.x * 32 + c4) = pk;
+            if (c4 == 0) ad[(size_t)tok * (ff >> 5) + blockIdx.x] = f2h(dd);
+        }
+    }
+    Q3_STAMP(6);
+    Q3_STAMP_FLUSH();
 }
 
 // -----------------------------------------------------------------------------------------------------

@@ -470,10 +470,21 @@ struct OnnxSession::Impl {
         v.push_back(std::make_shared<DevBuf<uint8_t>>(bytes));
         return v.back();
     }
+    // every tensor is made here: a shape computed from graph data (Reshape / Expand / ConstantOfShape / Tile ... operands) with a negative
+    // dimension or an element count that overflows becomes an Error before any buffer is sized from it
+    static int64_t checked_numel(const std::vector<int64_t>& shape) {
+        int64_t n = 1;
+        for (auto d : shape) {
+            Q3_CHECK(d >= 0, "tensor shape has a negative dimension");
+            Q3_CHECK(!__builtin_mul_overflow(n, d, &n) && n <= ((int64_t)1 << 33), "tensor element count overflows / exceeds 2^33");
+        }
+        return n;
+    }
     XTensor dev_tensor(int dtype, const std::vector<int64_t>& shape) {
-        XTensor t; t.dtype = dtype; t.shape = shape; t.dev = alloc((size_t)std::max<int64_t>(t.numel(), 1) * t.esize()); return t;
+        XTensor t; t.dtype = dtype; t.shape = shape; t.dev = alloc((size_t)std::max<int64_t>(checked_numel(shape), 1) * t.esize()); return t;
     }
     static XTensor host_tensor(int dtype, const std::vector<int64_t>& shape, std::vector<double> v) {
+        Q3_CHECK((size_t)checked_numel(shape) == v.size(), "host tensor: " + std::to_string(v.size()) + " values for a shape of " + std::to_string(checked_numel(shape)) + " elements");
         XTensor t; t.dtype = dtype; t.shape = shape; t.on_host = true; t.hv = std::move(v); return t;
     }
     float* f(const XTensor& t) const { return reinterpret_cast<float*>(t.dev->p); }
@@ -543,6 +554,8 @@ struct OnnxSession::Impl {
     }
     static std::vector<int64_t> nomod(size_t r) { return std::vector<int64_t>(r, std::numeric_limits<int64_t>::max()); }
     XTensor transpose(const XTensor& in, const std::vector<int64_t>& perm) {
+        Q3_CHECK(perm.size() == in.shape.size(), "Transpose: perm has " + std::to_string(perm.size()) + " entries for a rank-" + std::to_string(in.shape.size()) + " tensor");
+        { std::vector<char> seen(perm.size(), 0); for (auto p : perm) { Q3_CHECK(p >= 0 && p < (int64_t)perm.size() && !seen[(size_t)p], "Transpose: perm is not a permutation"); seen[(size_t)p] = 1; } }
         const auto st = strides_of(in.shape);
         std::vector<int64_t> os(perm.size()), is(perm.size());
         for (size_t d = 0; d < perm.size(); d++) { os[d] = in.shape[(size_t)perm[d]]; is[d] = st[(size_t)perm[d]]; }
@@ -617,6 +630,33 @@ struct OnnxSession::Impl {
     std::vector<int64_t> norm_axes(std::vector<int64_t> axes, int rank) { for (auto& a : axes) { if (a < 0) a += rank; Q3_CHECK(a >= 0 && a < rank, "axis out of range"); } std::sort(axes.begin(), axes.end()); axes.erase(std::unique(axes.begin(), axes.end()), axes.end()); return axes; }
 };
 
+// Decodes a TensorProto payload into doubles after checking it against the declared dims: the element count is computed with overflow
+// checks and capped, raw_data / the typed repeated field must hold at least that many elements (a truncated or crafted file must become
+// an Error, not a read past the mapped file), and element types without a decoder are refused instead of becoming zeros.
+static std::vector<double> tensor_values(const OnnxTensor& t, const std::string& what, int* dtype_out) {
+    int64_t n = 1;
+    for (auto d : t.dims) {
+        Q3_CHECK(d >= 0, what + ": negative dimension");
+        Q3_CHECK(!__builtin_mul_overflow(n, d, &n) && n <= ((int64_t)1 << 31), what + ": element count overflows / exceeds 2^31");
+    }
+    auto need_raw = [&](size_t esz) { Q3_CHECK(t.raw_bytes / esz >= (size_t)n, what + ": raw_data holds " + std::to_string(t.raw_bytes) + " bytes, dims need " + std::to_string((size_t)n * esz)); };
+    auto need_typed = [&](size_t have) { Q3_CHECK(have >= (size_t)n, what + ": typed data holds " + std::to_string(have) + " elements, dims need " + std::to_string(n)); };
+    std::vector<double> v((size_t)n);
+    int dtype = 1;
+    auto rd = [&](auto* typed) { for (int64_t i = 0; i < n; i++) v[(size_t)i] = (double)typed[i]; };
+    switch (t.data_type) {
+        case 1: if (t.raw) { need_raw(4); rd(reinterpret_cast<const float*>(t.raw)); } else { need_typed(t.float_data.size()); rd(t.float_data.data()); } break;
+        case 7: dtype = 7; if (t.raw) { need_raw(8); rd(reinterpret_cast<const int64_t*>(t.raw)); } else { need_typed(t.int64_data.size()); rd(t.int64_data.data()); } break;
+        case 6: dtype = 7; if (t.raw) { need_raw(4); rd(reinterpret_cast<const int32_t*>(t.raw)); } else { need_typed(t.int32_data.size()); rd(t.int32_data.data()); } break;
+        case 9: dtype = 9; if (t.raw) { need_raw(1); rd(reinterpret_cast<const uint8_t*>(t.raw)); } else { need_typed(t.int32_data.size()); rd(t.int32_data.data()); } break;
+        case 11: Q3_CHECK(t.raw || n == 0, what + ": double tensor without raw_data is not supported"); if (n) { need_raw(8); rd(reinterpret_cast<const double*>(t.raw)); } break;
+        case 10: { Q3_CHECK(t.raw || n == 0, what + ": f16 tensor without raw_data"); if (n) { need_raw(2); const uint16_t* h = reinterpret_cast<const uint16_t*>(t.raw); for (int64_t i = 0; i < n; i++) v[(size_t)i] = (double)q3_f16_to_f32(h[i]); } break; }
+        default: throw Error(what + ": element type " + std::to_string(t.data_type) + " is not supported");
+    }
+    if (dtype_out) *dtype_out = dtype;
+    return v;
+}
+
 OnnxSession::OnnxSession(const std::string& path, int device) : model_(new OnnxModel(path)), impl_(new Impl()), device_(device) {
     Q3_HIP(hipSetDevice(device_));
     impl_->launches = &launches_;
@@ -625,19 +665,9 @@ OnnxSession::OnnxSession(const std::string& path, int device) : model_(new OnnxM
     else if (model_->opsets.count("ai.onnx")) impl_->opset = model_->opsets.at("ai.onnx");
     for (const auto& t : model_->initializers) {
         Q3_CHECK(!t.external, "initializer " + t.name + " keeps its data in an external file");
-        const int64_t n = t.elements();
-        std::vector<double> v((size_t)n);
-        auto rd = [&](auto* typed, size_t cnt) { for (size_t i = 0; i < cnt && i < (size_t)n; i++) v[i] = (double)typed[i]; };
         int dtype = 1;
-        switch (t.data_type) {
-            case 1: if (t.raw) rd(reinterpret_cast<const float*>(t.raw), t.raw_bytes / 4); else rd(t.float_data.data(), t.float_data.size()); break;
-            case 7: dtype = 7; if (t.raw) rd(reinterpret_cast<const int64_t*>(t.raw), t.raw_bytes / 8); else rd(t.int64_data.data(), t.int64_data.size()); break;
-            case 6: dtype = 7; if (t.raw) rd(reinterpret_cast<const int32_t*>(t.raw), t.raw_bytes / 4); else rd(t.int32_data.data(), t.int32_data.size()); break;
-            case 9: dtype = 9; if (t.raw) rd(reinterpret_cast<const uint8_t*>(t.raw), t.raw_bytes); else rd(t.int32_data.data(), t.int32_data.size()); break;
-            case 11: if (t.raw) rd(reinterpret_cast<const double*>(t.raw), t.raw_bytes / 8); break;
-            case 10: { Q3_CHECK(t.raw, "f16 initializer without raw data"); const uint16_t* h = reinterpret_cast<const uint16_t*>(t.raw); for (int64_t i = 0; i < n; i++) v[(size_t)i] = (double)q3_f16_to_f32(h[i]); break; }
-            default: throw Error("initializer " + t.name + ": element type " + std::to_string(t.data_type) + " is not supported");
-        }
+        std::vector<double> v = tensor_values(t, "initializer " + t.name, &dtype);
+        const int64_t n = (int64_t)v.size();
         XTensor h = Impl::host_tensor(dtype, t.dims, std::move(v));
         // integer tensors and tiny float tensors (scalars, epsilons) stay on the host; weights go to HBM once
         impl_->consts[t.name] = (dtype == 7 || n <= 8) ? h : impl_->to_device(h);
@@ -651,7 +681,10 @@ std::vector<std::string> OnnxSession::unsupported_ops() const {
     return std::vector<std::string>(s.begin(), s.end());
 }
 
+// set_input / zeros / fetch / run allocate, copy and synchronise synchronously on the null stream: they take capture_mutex() so that they are safe
+// beside a running engine whose scheduler thread may be capturing a frame graph (q3_common.h)
 void OnnxSession::set_input(const std::string& name, int dtype, const void* data, const std::vector<int64_t>& shape) {
+    std::lock_guard<std::mutex> cap(capture_mutex());
     Q3_HIP(hipSetDevice(device_));
     Q3_CHECK(dtype == 1 || dtype == 7, "inputs are f32 or i64");
     XTensor t = impl_->dev_tensor(dtype, shape);
@@ -660,6 +693,7 @@ void OnnxSession::set_input(const std::string& name, int dtype, const void* data
 }
 void OnnxSession::bind_input(const std::string& name, const XTensor& t) { impl_->inputs[name] = t; }
 XTensor OnnxSession::zeros(int dtype, const std::vector<int64_t>& shape) {
+    std::lock_guard<std::mutex> cap(capture_mutex());
     Q3_HIP(hipSetDevice(device_));
     XTensor t = impl_->dev_tensor(dtype, shape);
     if (t.numel()) Q3_HIP(hipMemset(t.dev->p, 0, (size_t)t.numel() * t.esize()));
@@ -678,11 +712,13 @@ void OnnxSession::fetch(const XTensor& t, void* dst, size_t cap) const {
         else for (size_t i = 0; i < n; i++) reinterpret_cast<float*>(dst)[i] = (float)t.hv[i];
         return;
     }
+    std::lock_guard<std::mutex> cap_lock(capture_mutex());
     Q3_HIP(hipDeviceSynchronize());
     if (n) Q3_HIP(hipMemcpy(dst, t.dev->p, n * t.esize(), hipMemcpyDeviceToHost));
 }
 
 void OnnxSession::run() {
+    std::lock_guard<std::mutex> cap(capture_mutex());
     Q3_HIP(hipSetDevice(device_));
     Impl& I = *impl_;
     I.vals.clear();
@@ -753,20 +789,9 @@ void OnnxSession::run() {
             } else if (op == "Constant") {
                 if (auto* a = nd.attr("value")) {
                     const OnnxTensor& t = a->t;
-                    const int64_t n = t.elements();
-                    std::vector<double> v((size_t)n);
-                    int dtype = t.data_type == 7 || t.data_type == 6 ? 7 : t.data_type == 9 ? 9 : 1;
-                    for (int64_t i = 0; i < n; i++) {
-                        switch (t.data_type) {
-                            case 1: v[(size_t)i] = t.raw ? (double)reinterpret_cast<const float*>(t.raw)[i] : (double)t.float_data[(size_t)i]; break;
-                            case 7: v[(size_t)i] = t.raw ? (double)reinterpret_cast<const int64_t*>(t.raw)[i] : (double)t.int64_data[(size_t)i]; break;
-                            case 6: v[(size_t)i] = t.raw ? (double)reinterpret_cast<const int32_t*>(t.raw)[i] : (double)t.int32_data[(size_t)i]; break;
-                            case 9: v[(size_t)i] = t.raw ? (double)t.raw[i] : (double)t.int32_data[(size_t)i]; break;
-                            case 11: v[(size_t)i] = reinterpret_cast<const double*>(t.raw)[i]; break;
-                            case 10: v[(size_t)i] = (double)q3_f16_to_f32(reinterpret_cast<const uint16_t*>(t.raw)[i]); break;
-                            default: throw Error("Constant of element type " + std::to_string(t.data_type));
-                        }
-                    }
+                    int dtype = 1;
+                    std::vector<double> v = tensor_values(t, "Constant " + nd.name, &dtype);
+                    const int64_t n = (int64_t)v.size();
                     XTensor h = Impl::host_tensor(dtype, t.dims, std::move(v));
                     out(0, (dtype == 7 || n <= 4096) ? h : I.to_device(h));
                 } else if (auto* a2 = nd.attr("value_float")) out(0, Impl::host_tensor(1, {}, {(double)a2->f}));
@@ -779,12 +804,9 @@ void OnnxSession::run() {
                 double v = 0; int dtype = 1;
                 if (auto* a = nd.attr("value")) {
                     const OnnxTensor& t = a->t;
-                    dtype = t.data_type == 7 || t.data_type == 6 ? 7 : t.data_type == 9 ? 9 : 1;
-                    if (t.data_type == 1) v = t.raw ? (double)*reinterpret_cast<const float*>(t.raw) : (double)t.float_data.at(0);
-                    else if (t.data_type == 7) v = t.raw ? (double)*reinterpret_cast<const int64_t*>(t.raw) : (double)t.int64_data.at(0);
-                    else if (t.data_type == 6) v = t.raw ? (double)*reinterpret_cast<const int32_t*>(t.raw) : (double)t.int32_data.at(0);
-                    else if (t.data_type == 9) v = t.raw ? (double)t.raw[0] : (double)t.int32_data.at(0);
-                    else throw Error("ConstantOfShape value type");
+                    const std::vector<double> tv = tensor_values(t, "ConstantOfShape " + nd.name + " value", &dtype);
+                    Q3_CHECK(tv.size() >= 1, "ConstantOfShape " + nd.name + ": empty value tensor");
+                    v = tv[0];
                 }
                 const int64_t n = prod(shape);
                 if (n <= 65536) out(0, Impl::host_tensor(dtype, shape, std::vector<double>((size_t)n, v)));
@@ -799,6 +821,9 @@ void OnnxSession::run() {
             } else if (op == "Cast") {
                 const int64_t to = ai("to", 1);
                 const XTensor& x = in(0);
+                // f64 (11) is carried as f32 (documented precision loss); f16 / bf16 / string targets would need a rounding pass this executor does not have
+                Q3_CHECK(to == 1 || to == 11 || to == 7 || to == 6 || to == 2 || to == 3 || to == 5 || to == 12 || to == 13 || to == 9,
+                         "Cast to element type " + std::to_string(to) + " is not supported (tensors are f32 / i64 / bool on this executor)");
                 const int dt = (to == 7 || to == 6 || to == 2 || to == 3 || to == 5 || to == 12 || to == 13) ? 7 : to == 9 ? 9 : 1;
                 if (x.on_host) {
                     XTensor o = x; o.dtype = dt;
@@ -849,8 +874,9 @@ void OnnxSession::run() {
             } else if (op == "Tile") {
                 const XTensor& x = in(0);
                 const auto rep = I.ints_of(in(1));
+                Q3_CHECK(rep.size() == x.shape.size(), "Tile: repeats has " + std::to_string(rep.size()) + " entries for a rank-" + std::to_string(x.shape.size()) + " tensor");
                 std::vector<int64_t> os(x.shape.size());
-                for (size_t d = 0; d < os.size(); d++) os[d] = x.shape[d] * rep.at(d);
+                for (size_t d = 0; d < os.size(); d++) { Q3_CHECK(rep[d] >= 0 && rep[d] <= (1 << 24), "Tile: repeat count out of range"); os[d] = x.shape[d] * rep[d]; }
                 std::vector<int64_t> mod = x.shape; for (auto& m : mod) m = std::max<int64_t>(m, 1);
                 out(0, I.nd_copy(x, os, strides_of(x.shape), mod, 0));
             } else if (op == "Slice") {
@@ -879,7 +905,10 @@ void OnnxSession::run() {
             } else if (op == "Split") {
                 const XTensor& x = in(0);
                 int64_t a = ai("axis", 0); if (a < 0) a += (int64_t)x.shape.size();
+                Q3_CHECK(a >= 0 && a < (int64_t)x.shape.size(), "Split: axis out of range");
                 std::vector<int64_t> sizes = has(1) ? I.ints_of(in(1)) : aints("split");
+                { int64_t tot = 0; for (auto z : sizes) { Q3_CHECK(z >= 0, "Split: negative size"); tot += z; } Q3_CHECK(sizes.empty() || tot == x.shape[(size_t)a], "Split: sizes do not add up to the axis length"); }
+                Q3_CHECK(sizes.empty() || sizes.size() <= nd.outputs.size(), "Split: more sizes than outputs");
                 if (sizes.empty()) {
                     const int64_t parts = (int64_t)nd.outputs.size(), dim = x.shape[(size_t)a], each = (dim + parts - 1) / parts;
                     for (int64_t i = 0; i < parts; i++) sizes.push_back(std::min(each, dim - i * each));
@@ -894,6 +923,11 @@ void OnnxSession::run() {
             } else if (op == "Concat") {
                 const int r = (int)in(0).shape.size();
                 int64_t a = ai("axis", 0); if (a < 0) a += r;
+                Q3_CHECK(a >= 0 && a < r, "Concat: axis out of range");
+                for (size_t i = 1; i < nd.inputs.size(); i++) {
+                    Q3_CHECK((int)in(i).shape.size() == r, "Concat: input " + std::to_string(i) + " (" + nd.inputs[i] + ") has rank " + std::to_string(in(i).shape.size()) + ", input 0 (" + nd.inputs[0] + ") rank " + std::to_string(r));
+                    for (int d = 0; d < r; d++) Q3_CHECK(d == a || in(i).shape[(size_t)d] == in(0).shape[(size_t)d], "Concat: inputs differ off the concatenation axis");
+                }
                 bool all_host = true; int dtype = in(0).dtype; int64_t total = 0;
                 for (size_t i = 0; i < nd.inputs.size(); i++) { all_host = all_host && in(i).on_host; total += in(i).shape.at((size_t)a); if (in(i).dtype != 7) dtype = in(i).dtype == 9 && dtype == 9 ? 9 : 1; }
                 std::vector<int64_t> os = in(0).shape; os[(size_t)a] = total;
@@ -926,6 +960,7 @@ void OnnxSession::run() {
             } else if (op == "Gather") {
                 const XTensor& x = in(0); const XTensor& idx = in(1);
                 int64_t a = ai("axis", 0); if (a < 0) a += (int64_t)x.shape.size();
+                Q3_CHECK(a >= 0 && a < (int64_t)x.shape.size(), "Gather: axis out of range");
                 const int64_t dim = x.shape.at((size_t)a), inner = prod(x.shape, (size_t)a + 1), outer = prod(x.shape, 0, (size_t)a), nidx = idx.numel();
                 std::vector<int64_t> os(x.shape.begin(), x.shape.begin() + a);
                 os.insert(os.end(), idx.shape.begin(), idx.shape.end());
@@ -1042,20 +1077,24 @@ void OnnxSession::run() {
             } else if (op == "LayerNormalization") {
                 const XTensor x = I.as_f32(in(0));
                 int64_t a = ai("axis", -1); if (a < 0) a += (int64_t)x.shape.size();
+                Q3_CHECK(a >= 0 && a < (int64_t)x.shape.size(), "LayerNormalization: axis out of range");
                 const int64_t cols = prod(x.shape, (size_t)a), rows = prod(x.shape, 0, (size_t)a);
                 XTensor g = has(1) ? I.as_f32(in(1)) : XTensor(), b = has(2) ? I.as_f32(in(2)) : XTensor();
+                Q3_CHECK((!has(1) || g.numel() == cols) && (!has(2) || b.numel() == cols), "LayerNormalization: scale / bias length does not match the normalised extent");
                 XTensor o = I.dev_tensor(1, x.shape);
                 if (rows && cols) { hipLaunchKernelGGL(k_norm_rows, dim3((unsigned)rows), dim3(256), 0, 0, I.f(o), I.f(x), has(1) ? I.f(g) : nullptr, has(2) ? I.f(b) : nullptr, cols, af("epsilon", 1e-5f), 0, (int64_t)1); I.count(); }
                 out(0, o);
             } else if (op == "InstanceNormalization") {
                 const XTensor x = I.as_f32(in(0)), g = I.as_f32(in(1)), b = I.as_f32(in(2));
                 const int64_t C = x.shape.at(1), rows = x.shape.at(0) * C, cols = prod(x.shape, 2);
+                Q3_CHECK(g.numel() == C && b.numel() == C, "InstanceNormalization: scale / bias length does not match the channels");
                 XTensor o = I.dev_tensor(1, x.shape);
                 if (rows && cols) { hipLaunchKernelGGL(k_norm_rows, dim3((unsigned)rows), dim3(256), 0, 0, I.f(o), I.f(x), I.f(g), I.f(b), cols, af("epsilon", 1e-5f), 1, C); I.count(); }
                 out(0, o);
             } else if (op == "BatchNormalization") {
                 const XTensor x = I.as_f32(in(0)), sc = I.as_f32(in(1)), bi = I.as_f32(in(2)), mean = I.as_f32(in(3)), var = I.as_f32(in(4));
                 const int64_t C = x.shape.at(1), inner = prod(x.shape, 2), n = x.numel();
+                Q3_CHECK(sc.numel() == C && bi.numel() == C && mean.numel() == C && var.numel() == C, "BatchNormalization: parameter lengths do not match the channels");
                 XTensor o = I.dev_tensor(1, x.shape);
                 if (n) { hipLaunchKernelGGL(k_batchnorm, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), I.f(sc), I.f(bi), I.f(mean), I.f(var), af("epsilon", 1e-5f), C, inner, n); I.count(); }
                 out(0, o);
@@ -1131,12 +1170,21 @@ void OnnxSession::run() {
                 XTensor x = I.as_f32(in(0)), w = I.as_f32(in(1)), b = has(2) ? I.as_f32(in(2)) : XTensor();
                 const int sp = (int)x.shape.size() - 2;
                 Q3_CHECK(sp == 1 || sp == 2, "convolutions over 1 or 2 spatial dimensions");
+                Q3_CHECK(w.shape.size() == x.shape.size(), op + ": weight rank does not match the input rank");
                 auto two = [&](std::vector<int64_t> v, int64_t fill) { if (v.empty()) v.assign((size_t)sp, fill); if (sp == 1) v.insert(v.begin(), fill == 0 ? 0 : 1); return v; };
                 std::vector<int64_t> strides = two(aints("strides"), 1), dil = two(aints("dilations"), 1), pads = aints("pads"), ks(w.shape.begin() + 2, w.shape.end());
                 if (sp == 1) ks.insert(ks.begin(), 1);
                 ConvArgs g{};
                 g.N = x.shape[0]; g.C = x.shape[1]; g.H = sp == 1 ? 1 : x.shape[2]; g.W = x.shape.back();
                 g.kh = ks[0]; g.kw = ks[1]; g.sh = strides[0]; g.sw = strides[1]; g.dh = dil[0]; g.dw = dil[1]; g.groups = ai("group", 1);
+                // operand shapes against what k_conv2d / k_convtr2d index (they divide by groups and strides and trust the weight / bias extents)
+                Q3_CHECK(strides.size() == 2 && dil.size() == 2 && (pads.empty() || pads.size() == (size_t)(2 * sp)), op + ": strides / dilations / pads do not match the spatial rank");
+                Q3_CHECK(g.sh > 0 && g.sw > 0 && g.dh > 0 && g.dw > 0 && g.kh > 0 && g.kw > 0, op + ": strides, dilations and kernel extents must be positive");
+                Q3_CHECK(g.groups > 0 && g.C % g.groups == 0, op + ": group does not divide the input channels");
+                if (op == "Conv") Q3_CHECK(w.shape[1] * g.groups == g.C && w.shape[0] % g.groups == 0, "Conv: weight shape [M, C/group, ...] does not match the input channels");
+                else Q3_CHECK(w.shape[0] == g.C, "ConvTranspose: weight shape [C, M/group, ...] does not match the input channels");
+                Q3_CHECK(!has(2) || b.numel() == (op == "Conv" ? w.shape[0] : w.shape[1] * g.groups), op + ": bias length does not match the output channels");
+                for (auto pv : pads) Q3_CHECK(pv >= 0, op + ": negative padding");
                 std::vector<int64_t> pb(2, 0), pe(2, 0);
                 if (!pads.empty()) { if (sp == 1) { pb[1] = pads[0]; pe[1] = pads[1]; } else { pb[0] = pads[0]; pb[1] = pads[1]; pe[0] = pads[2]; pe[1] = pads[3]; } }
                 const std::string ap = as("auto_pad", "NOTSET");
@@ -1255,9 +1303,20 @@ void OnnxSession::run() {
                 const int rank = (int)x.shape.size();
                 ResizeArgs a{}; a.rank = rank;
                 std::vector<int64_t> os = x.shape;
-                if (has(3)) { os = I.ints_of(in(3)); Q3_CHECK((int)os.size() == rank, "Resize sizes rank"); for (int d = 0; d < rank; d++) a.scale[d] = (float)os[(size_t)d] / (float)x.shape[(size_t)d]; }
-                else { Q3_CHECK(has(2), "Resize needs scales or sizes"); const XTensor sc = I.to_host(in(2)); Q3_CHECK((int)sc.hv.size() == rank, "Resize scales rank");
-                       for (int d = 0; d < rank; d++) { a.scale[d] = (float)sc.hv[(size_t)d]; os[(size_t)d] = (int64_t)std::floor((double)x.shape[(size_t)d] * sc.hv[(size_t)d]); } }
+                Q3_CHECK(rank >= 1 && rank <= 8, "Resize: rank out of range");
+                const bool old_layout = I.opset < 11; // opset 10: inputs (X, scales); opset >= 11: (X, roi, scales, sizes)
+                if (!old_layout && has(3)) { os = I.ints_of(in(3)); Q3_CHECK((int)os.size() == rank, "Resize sizes rank"); for (int d = 0; d < rank; d++) { Q3_CHECK(x.shape[(size_t)d] > 0 && os[(size_t)d] >= 0, "Resize: empty input extent"); a.scale[d] = (float)os[(size_t)d] / (float)x.shape[(size_t)d]; } }
+                else { const int si = old_layout ? 1 : 2; Q3_CHECK(has(si), "Resize needs scales or sizes"); const XTensor sc = I.to_host(in(si)); Q3_CHECK((int)sc.hv.size() == rank, "Resize scales rank");
+                       for (int d = 0; d < rank; d++) { Q3_CHECK(sc.hv[(size_t)d] > 0, "Resize: scales must be positive"); a.scale[d] = (float)sc.hv[(size_t)d]; os[(size_t)d] = (int64_t)std::floor((double)x.shape[(size_t)d] * sc.hv[(size_t)d]); } }
+                { // the kernel samples x_in = floor(x_out / scale) (asymmetric + floor).  ONNX defaults to half_pixel + round_prefer_floor, which picks the same
+                  // sample exactly when every scale is a whole number >= 1; any other combination is refused instead of silently resampling differently
+                    const std::string ctm = as("coordinate_transformation_mode", old_layout ? "asymmetric" : "half_pixel"), nm = as("nearest_mode", old_layout ? "floor" : "round_prefer_floor");
+                    bool whole = true;
+                    for (int d = 0; d < rank; d++) whole = whole && a.scale[d] >= 1.0f && a.scale[d] == std::floor(a.scale[d]);
+                    const bool native = ctm == "asymmetric" && nm == "floor";
+                    const bool equivalent = whole && (ctm == "half_pixel" || ctm == "pytorch_half_pixel" || ctm == "asymmetric") && (nm == "round_prefer_floor" || nm == "floor");
+                    Q3_CHECK(native || equivalent, "Resize: coordinate_transformation_mode=" + ctm + " nearest_mode=" + nm + " is only implemented for whole-number up-scaling");
+                }
                 for (int d = 0; d < rank; d++) { a.oshape[d] = os[(size_t)d]; a.ishape[d] = x.shape[(size_t)d]; }
                 XTensor o = I.dev_tensor(1, os);
                 const int64_t n = o.numel();
@@ -1265,8 +1324,10 @@ void OnnxSession::run() {
                 out(0, o);
             } else if (op == "GroupNormalization") {
                 const XTensor x = I.as_f32(in(0)), g = I.as_f32(in(1)), b = I.as_f32(in(2));
-                const int64_t G = ai("num_groups", 1), C = x.shape.at(1), sp = prod(x.shape, 2), rows = x.shape.at(0) * G, cols = (C / G) * sp;
+                const int64_t G = ai("num_groups", 1), C = x.shape.at(1), sp = prod(x.shape, 2);
                 Q3_CHECK(G > 0 && C % G == 0, "GroupNormalization groups");
+                const int64_t rows = x.shape.at(0) * G, cols = (C / G) * sp;
+                Q3_CHECK((g.numel() == C || g.numel() == G) && b.numel() == g.numel(), "GroupNormalization: scale / bias length is neither the channels nor the groups");
                 XTensor nrm = I.dev_tensor(1, x.shape);
                 if (rows && cols) { hipLaunchKernelGGL(k_norm_rows, dim3((unsigned)rows), dim3(256), 0, 0, I.f(nrm), I.f(x), (const float*)nullptr, (const float*)nullptr, cols, af("epsilon", 1e-5f), 0, (int64_t)1); I.count(); }
                 // per-channel affine (opset 21 form; opset 18 files carry per-group scale / bias of length G)

@@ -22,7 +22,7 @@ struct OnnxTensor {       // TensorProto
     const uint8_t* raw = nullptr; size_t raw_bytes = 0;   // raw_data (points into the mapped file)
     std::vector<float> float_data; std::vector<int64_t> int64_data; std::vector<int32_t> int32_data; // typed repeated fields
     bool external = false;                                 // data_location = EXTERNAL: payload lives in a side file (not loaded)
-    int64_t elements() const { int64_t n = 1; for (auto d : dims) n *= d; return n; }
+    int64_t elements() const { int64_t n = 1; for (auto d : dims) if (d < 0 || __builtin_mul_overflow(n, d, &n)) return -1; return n; } // -1: negative dim / overflow
 };
 struct OnnxAttr {         // AttributeProto
     std::string name; int32_t type = 0; // 1 FLOAT 2 INT 3 STRING 4 TENSOR 6 FLOATS 7 INTS

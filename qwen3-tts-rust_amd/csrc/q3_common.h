@@ -8,6 +8,7 @@
 #include <string>
 #include <vector>
 #include <stdexcept>
+#include <mutex>
 #include "../../include/q3tts_spec.h"
 
 namespace q3 {
@@ -17,6 +18,12 @@ void set_last_error(const std::string& s);
 const char* last_error();
 
 struct Error : std::runtime_error { using std::runtime_error::runtime_error; };
+
+// Process-wide lock around frame-graph construction (stream capture).  On ROCm 7.2 a synchronous hipMemcpy / hipMalloc / hipDeviceSynchronize on
+// ANY thread while another thread captures fails ("would make the legacy stream depend on a capturing blocking stream") and invalidates the
+// capture, thread-local capture mode notwithstanding; code that must allocate, copy or synchronise synchronously while engines may be running
+// (voice registration, codec state export / import / reset, the ONNX executor) takes this lock.  Defined in engine.cpp.
+std::mutex& capture_mutex();
 
 #define Q3_HIP(expr) do { hipError_t e_ = (expr); if (e_ != hipSuccess) { \
     throw ::q3::Error(std::string(#expr) + ": " + hipGetErrorString(e_) + " at " __FILE__ ":" + std::to_string(__LINE__)); } } while (0)

@@ -72,7 +72,7 @@ SYMBOLS = [
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
     "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
     "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
-    "q3tts_text_nfc", "q3tts_op_gemv_kq", "q3tts_op_gateup_kq", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_decode",
+    "q3tts_text_nfc", "q3tts_op_gemv_kq", "q3tts_op_gateup_kq", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_fetch", "q3tts_onnx_decoder_decode",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]
@@ -460,15 +460,15 @@ class Decoder:  # AudioDecoder (onnx.rs:324-496)
         L = lib()
         L.q3tts_decoder_state_floats.restype = C.c_int64
         L.q3tts_decoder_state_floats.argtypes = [C.c_void_p]
-        L.q3tts_decoder_state_export.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        L.q3tts_decoder_state_export.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         buf = np.zeros(L.q3tts_decoder_state_floats(self.h), np.float32)
-        _chk(L.q3tts_decoder_state_export(self.h, stream, _p(buf)))
+        _chk(L.q3tts_decoder_state_export(self.h, stream, _p(buf), buf.size))
         return buf
 
     def state_import(self, blob, stream=0):
-        lib().q3tts_decoder_state_import.argtypes = [C.c_void_p, C.c_int32, C.c_void_p]
+        lib().q3tts_decoder_state_import.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int64]
         blob = np.ascontiguousarray(blob, np.float32)
-        _chk(lib().q3tts_decoder_state_import(self.h, stream, _p(blob)))
+        _chk(lib().q3tts_decoder_state_import(self.h, stream, _p(blob), blob.size))
 
     def state_layout(self):
         L = lib()
@@ -648,7 +648,12 @@ class OnnxDecoder:
         codes = np.ascontiguousarray(codes, np.int64).reshape(-1, 16)
         out = np.zeros(max(codes.shape[0], 1) * max_samples_per_frame, np.float32)
         n = C.c_int64()
-        _chk(lib().q3tts_onnx_decoder_decode(self.h, codes.ctypes.data, codes.shape[0], 1 if is_final else 0, out.ctypes.data, out.size, C.byref(n)))
+        rc = lib().q3tts_onnx_decoder_decode(self.h, codes.ctypes.data, codes.shape[0], 1 if is_final else 0, out.ctypes.data, out.size, C.byref(n))
+        if rc == 2:  # buffer too small: the chunk is kept in the handle, fetch it again into one that fits
+            out = np.zeros(n.value, np.float32)
+            lib().q3tts_onnx_decoder_fetch.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.POINTER(C.c_int64)]
+            rc = lib().q3tts_onnx_decoder_fetch(self.h, out.ctypes.data, out.size, C.byref(n))
+        _chk(rc)
         return out[: n.value].copy()
 
 

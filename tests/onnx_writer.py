@@ -40,7 +40,9 @@ def _vi(field, value):
 
 def tensor(name, arr, typed=False):
     """TensorProto; typed=True stores float_data / int64_data (packed) instead of raw_data"""
-    arr = np.ascontiguousarray(arr)
+    arr = np.asarray(arr)
+    if arr.ndim and not arr.flags.c_contiguous:   # (np.ascontiguousarray would turn a 0-d scalar into a 1-element vector)
+        arr = np.ascontiguousarray(arr)
     dt = F32 if arr.dtype == np.float32 else I64
     out = b"".join(_vi(1, d) for d in arr.shape) + _vi(2, dt)
     if typed and dt == F32:

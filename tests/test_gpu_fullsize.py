@@ -43,28 +43,77 @@ def test_fullsize_parity_and_properties(gpu, oracle, full_model, vivian):
 
 
 def test_fullsize_batched_c3_shapes_vs_oracle_singles(gpu, oracle, full_model, vivian):
-    """BASELINE config C3 at its real dimensions: 32 slots of the full Q3TTS-1.7B-synth model step together, so every batched
-    (>= 16 token) kernel form runs at K = 2048 / 6144 (talker) and K = 1024 / 3072 (predictor, incl. the fused gate/up matrix-core
-    kernel that the tiny model's K = 256 cannot reach), the multi-sequence prefill packs 32 prompts, and continuous batching retires
-    slots at different frames.  Three of the 32 requests are compared with the oracle run ALONE on the host: tokens bit-exact."""
-    ge = gpu.Engine(full_model, "q8_0", max_batch=32, max_steps=16, load_codec=False)
+    """BASELINE config C3 as bench.py runs it: 64 slots of the full Q3TTS-1.7B-synth model step together (the 64-wide frame graph, every
+    batched kernel form at K = 2048 / 6144 (talker) and K = 1024 / 3072 (predictor), the multi-sequence prefill over the bench's
+    27 / 43 / 75-row prompts on the async lane, 4 codec groups over 2 lanes, two codec chunks per stream), ragged lengths so continuous
+    batching retires slots at different frames.  Three of the 64 requests are compared with the oracle run ALONE on the host (tokens
+    bit-exact), one with the oracle codec (PCM 1e-4 RMS), and one request alone must give the tokens and PCM it gave inside the batch."""
+    ge = gpu.Engine(full_model, "q8_0", max_batch=64, max_steps=16, load_codec=True)
     prompts = []
-    for i in range(32):
+    for i in range(64):
         rng = np.random.default_rng(500 + i)
-        prompts.append(ge.assets.build_core(rng.integers(0, 4000, 3 + (i % 3)).astype(np.int32), lang_id=2055, spk_emb=vivian))
-    assert prompts[0].shape == (14, 2048)
-    ms = [3 + (i % 4) for i in range(32)]            # ragged lengths: slots retire at different frames
-    res = ge.generate_batch(prompts, max_steps=ms, mask_eos=True)
+        prompts.append(ge.assets.build_core(rng.integers(0, 4000, (16, 32, 64)[i % 3]).astype(np.int32), lang_id=2055, spk_emb=vivian))
+    assert [p.shape[0] for p in prompts[:3]] == [27, 43, 75]
+    ms = [8 + (i % 4) for i in range(64)]            # ragged lengths (8..11 frames: two codec chunks + a partial one per stream)
+    res = ge.generate_batch(prompts, max_steps=ms, mask_eos=True, want_pcm=True)
     st = ge.stats()
-    assert st["slot_frames"] / max(st["graph_frames"], 1) >= 16, "the batched (>= 16 token) graph widths were not exercised"
+    assert st["slot_frames"] / max(st["graph_frames"], 1) >= 48, "the 64-wide frame graph was not exercised"
     for r, m in zip(res, ms):
         assert r["codes"].shape == (m, 16) and r["codes"].min() >= 0 and r["codes"][:, 0].max() < 2160 and r["codes"][:, 1:].max() < 2048
-    oe = oracle.Engine(os.path.join(full_model, "gguf_q8_0"), None, 8)
-    for i in (0, 13, 31):
+        assert r["pcm"].size == m * 1920 and np.isfinite(r["pcm"]).all()
+    oe = oracle.Engine(os.path.join(full_model, "gguf_q8_0"), None, 16)
+    for i in (0, 13, 62):                             # one prompt of each length (27 / 43 / 75 rows)
         oc, _ = oe.generate(prompts[i], max_steps=3, mask_eos=True)
         assert np.array_equal(oc, res[i]["codes"][:3]), i
     oe.close()
-    # batch invariance at full size: the same request alone gives the same tokens
+    oc2 = oracle.Codec(os.path.join(full_model, "onnx", "q3tts_codec.gguf")); oc2.reset()
+    ref = oc2.decode(np.clip(res[40]["codes"][:5], 0, 2047)).copy(); oc2.close()
+    assert np.sqrt(np.mean((ref - res[40]["pcm"][: ref.size]) ** 2)) < 1e-4
+    # batch invariance at full size: the same request alone gives the same tokens and the same PCM (1e-6: the codec's batched GEMMs tile by rows)
+    solo = ge.generate_batch([prompts[7]], max_steps=ms[7], mask_eos=True, want_pcm=True)[0]
+    assert np.array_equal(solo["codes"], res[7]["codes"])
+    assert np.sqrt(np.mean((solo["pcm"] - res[7]["pcm"]) ** 2)) < 1e-5
+    ge.close()
+
+
+@pytest.fixture(scope="module")
+def full_model_bf16(synth_tool, full_model):
+    marker = os.path.join(full_model, ".complete_bf16")
+    if not os.path.exists(marker):
+        subprocess.check_call([synth_tool, "--out", full_model, "--preset", "full", "--quant", "bf16", "--seed", "1234"])
+        open(marker, "w").write("ok")
+    return full_model
+
+
+def test_fullsize_c5_bf16_clone_batch32_vs_oracle(gpu, oracle, full_model_bf16, vivian):
+    """BASELINE config C5 at its real dimensions (engine.rs:243-302 clone path): bf16 weights, 32 slots, 133-row voice-clone prompts (62 reference
+    frames + 24 reference-text ids + 32 text ids) over 4 registered voices.  The 32 x 133 = 4 256-row prefill runs k_gemm_float_mfma's >= 96-token
+    form at K = 2048 / 6144 and the 32-token steps its narrow form at K = 1024 / 3072.  Three requests (three different voices) against the
+    oracle run alone on the host for 3 frames, bit-exact; the same request alone == inside the batch."""
+    ge = gpu.Engine(full_model_bf16, "bf16", max_batch=32, max_prompt=256, max_steps=16, load_codec=False)
+    voices = []
+    for v in range(4):
+        vr = np.random.default_rng(1000 + v)
+        voices.append(dict(spk=(vivian * (1.0 - 0.1 * v) + 0.01 * vr.standard_normal(2048)).astype(np.float32),
+                           codes=vr.integers(0, 2048, 62 * 16).astype(np.int32), text=vr.integers(0, 4000, 24).astype(np.int32)))
+    vids = [ge.register_voice(v["spk"], v["codes"], v["text"]) for v in voices]
+    texts = [np.random.default_rng(42 + i).integers(0, 4000, 32).astype(np.int32) for i in range(32)]
+    prompts = [ge.assets.build_clone(texts[i], voices[i % 4]["codes"], voices[i % 4]["text"], voices[i % 4]["spk"]) for i in range(32)]
+    assert prompts[0].shape == (133, 2048)
+    ms = [4 + (i % 3) for i in range(32)]
+    ids = [ge.submit_text(vids[i % 4], texts[i], lang_id=2055, max_steps=ms[i], temperature=0.0, seed=42) for i in range(32)]
+    while ge.sched_step():
+        pass
+    res = [ge.result(rid) for rid in ids]
+    st = ge.stats()
+    assert st["slot_frames"] / max(st["graph_frames"], 1) >= 24, "the 32-wide frame graph was not exercised"
+    for r, m in zip(res, ms):
+        assert r["codes"].shape == (m, 16) and r["codes"].min() >= 0 and r["codes"][:, 0].max() < 2160 and r["codes"][:, 1:].max() < 2048
+    oe = oracle.Engine(os.path.join(full_model_bf16, "gguf_bf16"), None, 16)
+    for i in (0, 13, 30):                             # voices 0, 1, 2
+        oc, _ = oe.generate(prompts[i], max_steps=3, mask_eos=True)
+        assert np.array_equal(oc, res[i]["codes"][:3]), i
+    oe.close()
     solo = ge.generate_batch([prompts[7]], max_steps=ms[7], mask_eos=True)[0]
     assert np.array_equal(solo["codes"], res[7]["codes"])
     ge.close()

@@ -615,3 +615,90 @@ def test_more_ops_trilu_scatter_resize_groupnorm(gpu, tmp_path):
     np.testing.assert_allclose(r["mish"], xd * np.tanh(np.log1p(np.exp(xd))), rtol=2e-5, atol=2e-6)
     np.testing.assert_allclose(r["celu"], np.maximum(0, xd) + np.minimum(0, 1.5 * (np.exp(xd / 1.5) - 1)), rtol=2e-5, atol=2e-6)
     np.testing.assert_array_equal(r["thr"], np.where(x > 0.3, x, 0))
+
+
+def _raw_tensor(name, dims, dtype, payload, field=9):
+    """TensorProto with dims and payload chosen independently (for malformed-file cases)"""
+    return b"".join(W._vi(1, d) for d in dims) + W._vi(2, dtype) + W._ld(field, payload) + W._s(8, name)
+
+
+def test_malformed_graphs_are_errors_not_faults(gpu, tmp_path):
+    """A truncated or crafted .onnx must become a clean error naming the tensor / node: payloads are checked against the declared dims
+    (initialisers, Constant, ConstantOfShape), element counts against overflow, and every interpreter launch against its operand shapes
+    (Conv groups / weight / bias extents, normalisation parameter lengths, Transpose perm, Concat / Split / Gather axes, Tile repeats)."""
+    x = np.arange(2 * 4 * 6, dtype=np.float32).reshape(2, 4, 6)
+    ok_w = np.ones((4, 4, 3), np.float32)
+
+    def expect_error(nodes, inits, feeds, outs, needle, opset=17):
+        with pytest.raises(Exception) as ei:
+            run_graph(gpu, tmp_path, nodes, inits, feeds, outs, opset=opset)
+        assert needle in str(ei.value), str(ei.value)
+
+    add = [W.node("Add", ["x", "w"], ["y"])]
+    yo = [("y", F32, [2, 4, 6])]
+    # initialiser payloads
+    expect_error(add, [_raw_tensor("w", [2, 4, 6], F32, b"\0" * (4 * 47))], {"x": x}, yo, "raw_data holds")                       # truncated raw_data
+    expect_error(add, [_raw_tensor("w", [2, 4, 6], F32, b"\0" * (4 * 10), field=4)], {"x": x}, yo, "typed data holds")            # short float_data
+    expect_error(add, [_raw_tensor("w", [1 << 40, 1 << 40], F32, b"\0" * 16)], {"x": x}, yo, "overflows")                          # element count overflow
+    expect_error(add, [_raw_tensor("w", [6], 11, b"")], {"x": x}, yo, "raw_data holds")                                            # double without data
+    expect_error(add, [_raw_tensor("w", [6], 16, b"\0" * 12)], {"x": x}, yo, "element type 16")                                    # bf16: no decoder
+    # Constant / ConstantOfShape attribute tensors
+    expect_error([W.node("Constant", [], ["w"], "c0", [W._s(1, "value") + W._ld(5, _raw_tensor("", [2, 4, 6], F32, b"\0" * 8)) + W._vi(20, 4)])] + add,
+                 [], {"x": x}, yo, "raw_data holds")
+    expect_error([W.node("ConstantOfShape", ["shp"], ["w"], "c1", [W._s(1, "value") + W._ld(5, _raw_tensor("", [1], F32, b"")) + W._vi(20, 4)])] + add,
+                 [W.tensor("shp", np.array([2, 4, 6], np.int64), typed=True)], {"x": x}, yo, "holds")
+    # operand shapes the kernels trust
+    conv = lambda attrs, w=ok_w, b=None: ([W.node("Conv", ["x", "w"] + (["b"] if b is not None else []), ["y"], "cv", attrs)],
+                                          [W.tensor("w", w)] + ([W.tensor("b", b)] if b is not None else []))
+    for attrs, w, b, needle in (([W.attr_int("group", 0)], ok_w, None, "group"), ([W.attr_int("group", 3)], ok_w, None, "group"),
+                                ([W.attr_ints("strides", [0])], ok_w, None, "positive"), ([], np.ones((4, 3, 3), np.float32), None, "weight shape"),
+                                ([], ok_w, np.ones(5, np.float32), "bias length"), ([W.attr_ints("pads", [1, 1, 1])], ok_w, None, "spatial rank")):
+        n, i = conv(attrs, w, b)
+        expect_error(n, i, {"x": x}, [("y", F32, [2, 4, 4])], needle)
+    expect_error([W.node("ConvTranspose", ["x", "w"], ["y"], "ct")], [W.tensor("w", np.ones((3, 2, 3), np.float32))], {"x": x}, [("y", F32, [2, 2, 8])], "weight shape")
+    one4, one3 = np.ones(4, np.float32), np.ones(3, np.float32)
+    expect_error([W.node("BatchNormalization", ["x", "s", "b", "m", "v"], ["y"], "bn")],
+                 [W.tensor("s", one4), W.tensor("b", one4), W.tensor("m", one3), W.tensor("v", one4)], {"x": x}, yo, "BatchNormalization")
+    expect_error([W.node("InstanceNormalization", ["x", "s", "b"], ["y"], "in")], [W.tensor("s", one3), W.tensor("b", one4)], {"x": x}, yo, "InstanceNormalization")
+    expect_error([W.node("LayerNormalization", ["x", "s"], ["y"], "ln", [W.attr_int("axis", -1)])], [W.tensor("s", one4)], {"x": x}, yo, "LayerNormalization")
+    expect_error([W.node("Transpose", ["x"], ["y"], "tp", [W.attr_ints("perm", [0, 0, 2])])], [], {"x": x}, yo, "permutation")
+    expect_error([W.node("Transpose", ["x"], ["y"], "tp", [W.attr_ints("perm", [0, 1, 2, 3])])], [], {"x": x}, yo, "perm has")
+    expect_error([W.node("Concat", ["x", "x"], ["y"], "cc", [W.attr_int("axis", 5)])], [], {"x": x}, yo, "axis out of range")
+    expect_error([W.node("Split", ["x"], ["y", "z"], "sp", [W.attr_int("axis", 1), W.attr_ints("split", [1, 2])])], [], {"x": x}, yo, "add up")
+    expect_error([W.node("Gather", ["x", "i"], ["y"], "ga", [W.attr_int("axis", 3)])], [W.tensor("i", np.array([0], np.int64), typed=True)], {"x": x}, yo, "axis out of range")
+    expect_error([W.node("Tile", ["x", "r"], ["y"], "ti")], [W.tensor("r", np.array([1, 2], np.int64), typed=True)], {"x": x}, yo, "repeats")
+    expect_error([W.node("Cast", ["x"], ["y"], "ca", [W.attr_int("to", 10)])], [], {"x": x}, yo, "Cast to element type 10")
+    # Resize: ONNX's default half_pixel + round_prefer_floor equals the implemented sampling for whole-number up-scaling only
+    sc2 = W.tensor("sc", np.array([1, 1, 2], np.float32)); sc15 = W.tensor("sc", np.array([1, 1, 1.5], np.float32))
+    r = run_graph(gpu, tmp_path, [W.node("Resize", ["x", "", "sc"], ["y"], "rs")], [sc2], {"x": x}, [("y", F32, [2, 4, 12])])
+    assert np.array_equal(r["y"], np.repeat(x, 2, axis=2))
+    expect_error([W.node("Resize", ["x", "", "sc"], ["y"], "rs")], [sc15], {"x": x}, [("y", F32, [2, 4, 9])], "whole-number")
+    r = run_graph(gpu, tmp_path, [W.node("Resize", ["x", "", "sc"], ["y"], "rs", [W.attr_str("coordinate_transformation_mode", "asymmetric"), W.attr_str("nearest_mode", "floor")])],
+                  [sc15], {"x": x}, [("y", F32, [2, 4, 9])])
+    assert np.array_equal(r["y"], x[:, :, (np.arange(9) / 1.5).astype(int)])
+    r = run_graph(gpu, tmp_path, [W.node("Resize", ["x", "sc"], ["y"], "rs10")], [sc2], {"x": x}, [("y", F32, [2, 4, 12])], opset=10)   # opset-10 input layout
+    assert np.array_equal(r["y"], np.repeat(x, 2, axis=2))
+
+
+def test_decoder_state_import_rejects_bad_blobs(gpu, tiny_model):
+    """q3tts_decoder_state_import validates the caller's length and the blob's trailer before committing: a blob of another size, a cached-position
+    count outside the attention window, NaN or negative counters are errors -- not out-of-range device indexing on the next decode."""
+    path = os.path.join(tiny_model, "onnx", "q3tts_codec.gguf")
+    rng = np.random.default_rng(3)
+    codes = rng.integers(0, 2048, (8, 16))
+    d = gpu.Decoder(path, n_streams=2)
+    d.reset(0)
+    d.decode(codes[:4], stream=0)
+    blob = d.state_export(0)
+    ref = d.decode(codes[4:], stream=0).copy()
+    for mutate in (lambda b: b[:-1], lambda b: np.concatenate([b, [0.0]]).astype(np.float32)):
+        with pytest.raises(Exception, match="floats"):
+            d.state_import(mutate(blob.copy()), stream=1)
+    for pos, bad in ((-2, 1e6), (-2, -1.0), (-2, float("nan")), (-2, 2.5), (-1, -4.0), (-1, float("inf")), (-1, float("nan"))):
+        b = blob.copy(); b[pos] = bad
+        with pytest.raises(Exception, match="state_import"):
+            d.state_import(b, stream=1)
+    d.reset(1)
+    d.state_import(blob, stream=1)                     # the untouched blob still restores, and nothing above was committed half-way
+    assert np.array_equal(d.decode(codes[4:], stream=1), ref)
+    d.close()

@@ -39,4 +39,26 @@ def test_no_single_rounding_f16_fma_in_any_kernel(tmp_path):
     # the float-weight matmul must be on the K = 1 f32 matrix instructions (exact fma chains), not on a K > 1 form that sums products first
     k = texts[[os.path.basename(s) for s in srcs].index("kernels.hip")]
     assert "v_mfma_f32_16x16x1_4b_f32" in k and "v_mfma_f32_32x32x1_2b_f32" in k
-    assert not re.search(r"v_mfma_f32_(?:32x32x2|16x16x4)_f32", k)
+    # ... with one exception: k_gemm_q8_tile1 builds its per-block scale tile d_x * d_w with the K = 2 form whose second k is fed zeros (one exact
+    # product of two f16 values per output, + 0 * 0): allowed there and nowhere else
+    funcs = re.split(r"\n(?=_Z\w+:)", k)
+    for fn in funcs:
+        if re.search(r"v_mfma_f32_(?:32x32x2|16x16x4)_f32", fn):
+            assert fn.startswith("_ZN2q315k_gemm_q8_tile1"), fn.split(":")[0]
+
+
+@pytest.mark.skipif(not os.path.exists(HIPCC), reason="hipcc not installed")
+def test_hot_q8_kernels_use_no_scratch(tmp_path):
+    """The batched int8 GEMMs sit at their 128-register budget (two 512-thread workgroups per CU); one spilled register gives the kernel a
+    private segment, and a kernel with scratch was measured ~2 us slower PER LAUNCH on MI355X (430 GEMM launches per frame).  Any edit that
+    tips the allocation over must fail here, not in the next bench."""
+    text = _asm(os.path.join(CSRC, "kernels.hip"), str(tmp_path))
+    meta = text[text.index("amdhsa.kernels"):]
+    seen = 0
+    for blk in meta.split("  - .agpr_count")[1:]:
+        name = re.search(r"\.name:\s+(\S+)", blk).group(1)
+        if "k_gemm_q8_mfma" in name or "k_gemm_q8_tile1" in name or "k_gemm_q8_tok" in name or "k_gemv_q8I" in name:
+            seen += 1
+            assert int(re.search(r"\.private_segment_fixed_size:\s+(\d+)", blk).group(1)) == 0, name
+            assert int(re.search(r"\.vgpr_count:\s+(\d+)", blk).group(1)) <= 128 or "k_gemm_q8_t" in name and "tok" in name or "k_gemv_q8I" in name, name
+    assert seen >= 5
