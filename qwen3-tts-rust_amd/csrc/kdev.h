@@ -6,6 +6,24 @@
 
 namespace q3 {
 
+// In-kernel phase stamps for scripts/ubench_chain.hip (built with -DQ3_STAMPS; the library build compiles them to nothing): thread 0 of every
+// workgroup stores the 100 MHz s_memrealtime counter at up to 8 points of the kernel, so a phase can be placed on one time axis across workgroups.
+#ifdef Q3_STAMPS
+static __device__ unsigned long long* g_q3_stamps = nullptr; // one per translation unit, set through the unit's Q3_STAMP_SETTER function
+#define Q3_STAMP_SETTER(name) void name(hipStream_t st, unsigned long long* p) { (void)hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q3_stamps), &p, sizeof(p), 0, hipMemcpyHostToDevice, st); (void)hipStreamSynchronize(st); }
+// stamps live in SGPRs until the kernel's last instruction block (no store, no branch inside the phases); `dep` ties the read to a value the phase produced
+#define Q3_STAMP_DECL unsigned long long q3_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long q3_c0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c0_) :: "memory")
+#define Q3_STAMP(k) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]) :: "memory")
+#define Q3_STAMP_AFTER(k, dep) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]), "+v"(dep) :: "memory")
+#define Q3_STAMP_FLUSH() do { unsigned long long q3_c1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c1_) :: "memory"); q3_st_[7] = q3_c1_ - q3_c0_; if (threadIdx.x == 0 && g_q3_stamps) for (int k_ = 0; k_ < 8; k_++) g_q3_stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k_] = q3_st_[k_]; } while (0)
+#else
+#define Q3_STAMP_SETTER(name)
+#define Q3_STAMP_DECL
+#define Q3_STAMP(k) do {} while (0)
+#define Q3_STAMP_AFTER(k, dep) do {} while (0)
+#define Q3_STAMP_FLUSH() do {} while (0)
+#endif
+
 __device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 // f32 -> f16, round-to-nearest-even of the *f32 value*.  The empty asm makes the operand opaque: without it the backend folds
 // `f2h(fma(a, b, c))` into v_fma_mixlo_f16, which rounds the exact a*b+c once to f16 and differs from the spec's

@@ -16,22 +16,7 @@
 
 namespace q3 {
 
-// In-kernel phase stamps for scripts/ubench_chain.hip (built with -DQ3_STAMPS; the library build compiles them to nothing): thread 0 of every
-// workgroup stores the 100 MHz s_memrealtime counter at up to 8 points of the kernel, so a phase can be placed on one time axis across workgroups.
-#ifdef Q3_STAMPS
-__device__ unsigned long long* g_q3_stamps = nullptr;
-void set_stamp_buffer(hipStream_t st, unsigned long long* p) { Q3_HIP(hipMemcpyToSymbolAsync(HIP_SYMBOL(g_q3_stamps), &p, sizeof(p), 0, hipMemcpyHostToDevice, st)); Q3_HIP(hipStreamSynchronize(st)); }
-// stamps live in SGPRs until the kernel's last instruction block (no store, no branch inside the phases); `dep` ties the read to a value the phase produced
-#define Q3_STAMP_DECL unsigned long long q3_st_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long q3_c0_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c0_) :: "memory")
-#define Q3_STAMP(k) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]) :: "memory")
-#define Q3_STAMP_AFTER(k, dep) asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_st_[k]), "+v"(dep) :: "memory")
-#define Q3_STAMP_FLUSH() do { unsigned long long q3_c1_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(q3_c1_) :: "memory"); q3_st_[7] = q3_c1_ - q3_c0_; if (threadIdx.x == 0 && g_q3_stamps) for (int k_ = 0; k_ < 8; k_++) g_q3_stamps[((size_t)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x) * 8 + k_] = q3_st_[k_]; } while (0)
-#else
-#define Q3_STAMP_DECL
-#define Q3_STAMP(k) do {} while (0)
-#define Q3_STAMP_AFTER(k, dep) do {} while (0)
-#define Q3_STAMP_FLUSH() do {} while (0)
-#endif
+Q3_STAMP_SETTER(set_stamp_buffer)
 
 // =====================================================================================================
 // Q8_0 GEMV / skinny GEMM (spec S3).  One wave = R rows x one 256-element segment; LPR = 64/R lanes share

@@ -16,6 +16,7 @@
 #include "q3_common.h"
 
 namespace q3 {
+Q3_STAMP_SETTER(set_stamp_buffer_fused)
 
 // ---------------------------------------------------------------------------------------------------
 // one wave: h = h_in (+ parts, in order); RMSNorm; quantise to LDS.  (same arithmetic as k_rmsnorm_quant)
@@ -563,6 +564,8 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
     __shared__ __attribute__((aligned(16))) uint16_t vcur_s[128];
     __shared__ float p_s[HPW][64];
     const int kvh = HPW == 2 ? blockIdx.x : blockIdx.x >> 1, h0 = HPW == 2 ? 2 * blockIdx.x : blockIdx.x; // first q head of this wave
+    Q3_STAMP_DECL;
+    Q3_STAMP(0);
     const bool writer = HPW == 2 || (blockIdx.x & 1) == 0;
     const int tok = blockIdx.y, lane = threadIdx.x;
     const float scale = 0.08838834764831845f;
@@ -622,6 +625,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
         }
     }
     __syncthreads();
+    Q3_STAMP(1);
     const bool valid = lane < n, cur = lane == slot;
     float a[HPW];
 #pragma unroll
@@ -637,6 +641,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
 #pragma unroll
             for (int hh = 0; hh < HPW; hh++) a[hh] = q3_fmaf(q_s[hh][8 * d8 + e], kf[e], a[hh]);
     }
+    Q3_STAMP_AFTER(2, a[0]);
     float L[HPW];
 #pragma unroll
     for (int hh = 0; hh < HPW; hh++) {
@@ -647,6 +652,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
         L[hh] = wave_sum_bfly(pv);
     }
     __syncthreads();
+    Q3_STAMP(3);
     const int dq = n_head * 128;
 #pragma unroll
     for (int hh = 0; hh < HPW; hh++) {
@@ -702,6 +708,8 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
             if ((dc & 3) == 0) ad[(size_t)tok * (dq >> 5) + hq * 4 + (dc >> 2)] = f2h(dd);
         }
     }
+    Q3_STAMP(6);
+    Q3_STAMP_FLUSH();
 }
 void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, int n_head, int n_kv, const float* q_norm_w,
                             const float* k_norm_w, float eps, const float* rope_cos, const float* rope_sin, int n_ctx,

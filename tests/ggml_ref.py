@@ -111,3 +111,67 @@ def read_gguf(path):
         nb = ROW_BYTES[ty](ne[0]) * rows
         tensors[name] = (ty, ne, data[start + off:start + off + nb])
     return kv, tensors
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# Encoders (test fixtures only): any VALID encoding of the public block formats will do -- the readers above define the format; these are
+# plain min/max quantisers, not ggml's search -- so a fixture can hold K-quant copies of weights that came from somewhere else (transformers).
+def enc_q5_k(w):
+    """w [n][k] f32 (k % 256 == 0) -> raw bytes [n][k/256][176] of Q5_K super-blocks: x ~ d*sc_j*q - dmin*m_j, q in 0..31, sc/m 6 bit"""
+    w = np.ascontiguousarray(w, np.float32)
+    n, k = w.shape
+    x = w.reshape(-1, 8, 32)                                   # [super-block][sub-block][32]
+    lo, hi = np.minimum(x.min(-1), 0.0), x.max(-1)
+    step = np.maximum(hi - lo, 1e-12) / 31.0                   # per sub-block step and (non-negative) offset
+    off = -lo
+    d = (step.max(-1) / 63.0).astype(np.float16).astype(np.float32)
+    dmin = (off.max(-1) / 63.0).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(step / np.maximum(d, 1e-30)[:, None]), 1, 63).astype(np.int32)
+    mq = np.clip(np.rint(off / np.maximum(dmin, 1e-30)[:, None]), 0, 63).astype(np.int32)
+    q = np.clip(np.rint((x + (dmin[:, None] * mq)[..., None]) / np.maximum(d[:, None] * sc, 1e-30)[..., None]), 0, 31).astype(np.int32)
+    out = np.zeros((x.shape[0], 176), np.uint8)
+    out[:, 0:2] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    out[:, 2:4] = dmin.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    s8 = np.zeros((x.shape[0], 12), np.int32)
+    for j in range(4):
+        s8[:, j] = sc[:, j] | ((sc[:, j + 4] >> 4) << 6)
+        s8[:, j + 4] = mq[:, j] | ((mq[:, j + 4] >> 4) << 6)
+        s8[:, j + 8] = (sc[:, j + 4] & 0xF) | ((mq[:, j + 4] & 0xF) << 4)
+    out[:, 4:16] = s8.astype(np.uint8)
+    qh = np.zeros((x.shape[0], 32), np.int32)
+    qs = np.zeros((x.shape[0], 128), np.int32)
+    for j in range(8):
+        jj, hib = j >> 1, j & 1
+        qs[:, 32 * jj:32 * jj + 32] |= (q[:, j] & 0xF) << (4 * hib)
+        qh |= (q[:, j] >> 4) << (2 * jj + hib)
+    out[:, 16:48] = qh.astype(np.uint8)
+    out[:, 48:176] = qs.astype(np.uint8)
+    return out.reshape(n, k // 256 * 176)
+
+
+def enc_q6_k(w):
+    """w [n][k] f32 -> raw bytes [n][k/256][210] of Q6_K super-blocks: x ~ d*sc_s*q, q in -32..31, sc int8 per 16 elements"""
+    w = np.ascontiguousarray(w, np.float32)
+    n, k = w.shape
+    x = w.reshape(-1, 16, 16)                                  # [super-block][16 sub-blocks][16]
+    amax = np.abs(x).max(-1)
+    step = np.maximum(amax, 1e-12) / 31.0
+    d = (step.max(-1) / 127.0).astype(np.float16).astype(np.float32)
+    sc = np.clip(np.rint(step / np.maximum(d, 1e-30)[:, None]), 1, 127).astype(np.int32)
+    q = np.clip(np.rint(x / np.maximum(d[:, None] * sc, 1e-30)[..., None]), -32, 31).astype(np.int32) + 32   # stored 0..63
+    q = q.reshape(-1, 256)
+    out = np.zeros((q.shape[0], 210), np.uint8)
+    ql = np.zeros((q.shape[0], 128), np.int32)
+    qh = np.zeros((q.shape[0], 64), np.int32)
+    for half in range(2):
+        base = 128 * half
+        for grp in range(4):                                   # elements base + 32*grp + l
+            v = q[:, base + 32 * grp:base + 32 * grp + 32]
+            col = 64 * half + (32 if grp & 1 else 0)
+            ql[:, col:col + 32] |= (v & 0xF) << (4 if grp >= 2 else 0)
+            qh[:, 32 * half:32 * half + 32] |= (v >> 4) << (2 * grp)
+    out[:, 0:128] = ql.astype(np.uint8)
+    out[:, 128:192] = qh.astype(np.uint8)
+    out[:, 192:208] = sc.astype(np.int8).view(np.uint8)
+    out[:, 208:210] = d.astype(np.float16).view(np.uint8).reshape(-1, 2)
+    return out.reshape(n, k // 256 * 210)

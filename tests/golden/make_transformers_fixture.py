@@ -2,7 +2,7 @@
 
     python tests/golden/make_transformers_fixture.py
 
-Writes tests/golden/qwen3_tf_f16.gguf (a 2-layer Qwen3 decoder with f16-representable random weights, llama.cpp tensor names)
+Writes tests/golden/qwen3_tf_f16.gguf (+ _q8_0 and _q5_k_m copies) (a 2-layer Qwen3 decoder with f16-representable random weights, llama.cpp tensor names)
 and tests/golden/qwen3_tf_expected.npz (input embeddings, final-norm hidden states and logits computed by the locally installed
 `transformers` Qwen3Model in float32, eager attention).  The -m gpu test test_gpu_parity.py::test_tf_eval_vs_transformers_fixture
 compares q3tts_tf_eval (the HIP path, nothing from oracle/) with these numbers; tests/test_golden_cpu.py compares the oracle with
@@ -75,8 +75,32 @@ def main():
     with torch.no_grad():
         h = m(inputs_embeds=x).last_hidden_state[0]
         lg = h @ out_w.T
+    # the same model as a Q5_K_M file (Q5_K for q / k / o / gate / up, Q6_K for v / down / output -- the mixture the reference's default
+    # quantisation ships, /root/reference/src/tts/engine.rs:91-95): the K-quant kernels (packed planes, Q8 activations, k_gemm_kq_mfma for the
+    # 24-token prefill) against `transformers` run on the DEQUANTISED weights, so what is left between the two is the activation quantisation
+    import ggml_ref as G
+    t5, deq = {}, {}
+    for name, a in t.items():
+        if getattr(a, "ndim", 0) == 2:
+            w = a.astype(np.float32)
+            six = any(name.endswith(sfx) for sfx in ("attn_v.weight", "ffn_down.weight")) or name == "output.weight"
+            raw = (G.enc_q6_k if six else G.enc_q5_k)(w)
+            t5[name] = (14 if six else 13, w.shape, raw.tobytes())
+            deq[name] = (G.deq_q6_k if six else G.deq_q5_k)(raw.reshape(-1), w.shape[1])
+        else:
+            t5[name] = a
+    write_gguf(os.path.join(HERE, "qwen3_tf_q5_k_m.gguf"), kv, t5)
+    with torch.no_grad():
+        for l in range(L):
+            p = "layers.%d." % l
+            for src, dst in (("self_attn.q_proj", "attn_q"), ("self_attn.k_proj", "attn_k"), ("self_attn.v_proj", "attn_v"), ("self_attn.o_proj", "attn_output"),
+                             ("mlp.gate_proj", "ffn_gate"), ("mlp.up_proj", "ffn_up"), ("mlp.down_proj", "ffn_down")):
+                dict(m.named_parameters())[p + src + ".weight"].copy_(torch.from_numpy(deq["blk.%d.%s.weight" % (l, dst)]))
+        h5 = m(inputs_embeds=x).last_hidden_state[0]
+        lg5 = h5 @ torch.from_numpy(deq["output.weight"]).T
     np.savez(os.path.join(HERE, "qwen3_tf_expected.npz"), x=x[0].numpy(), hidden=h.numpy(), logits=lg.numpy(),
-             meta=np.array([D, L, H, HKV, FF, V, N], np.int32))
+             hidden_q5=h5.numpy(), logits_q5=lg5.numpy(), meta=np.array([D, L, H, HKV, FF, V, N], np.int32))
+    print("Q5_K_M copy: |hidden - hidden_q5| max %.3f (weight quantisation alone)" % float((h - h5).abs().max()))
     print("wrote fixture: %d tokens, |hidden| max %.3f, |logits| max %.3f" % (N, float(h.abs().max()), float(lg.abs().max())))
 
 

@@ -312,6 +312,45 @@ def test_tf_eval_vs_transformers_fixture(gpu):
         h1, l1 = gq.eval(g["x"][i:i + 1], pos[i:i + 1], 0, V)
         check_q(h1[0], l1[0], i)
     gq.close()
+    # the Q5_K_M copy (Q5_K + Q6_K rows, packed planes; 24-token prefill = k_gemm_kq_mfma, then the fused K-quant decode path token by token) against
+    # `transformers` run on the DEQUANTISED weights (hidden_q5 / logits_q5): only the activation quantisation separates the two (bar 6e-2)
+    g5 = gpu.TfContext(os.path.join(ROOT, "tests", "golden", "qwen3_tf_q5_k_m.gguf"), 64, 32)
+
+    def check_5(h, lg, i):
+        assert np.abs(h - g["hidden_q5"][i]).max() < 6e-2 * max(1.0, np.abs(g["hidden_q5"][i]).max()), i
+        assert np.abs(lg - g["logits_q5"][i]).max() < 6e-2 * max(1.0, np.abs(g["logits_q5"][i]).max()), i
+
+    h5, l5 = g5.eval(g["x"], pos, 0, V)
+    for i in range(N):
+        check_5(h5[i], l5[i], i)
+    g5.clear()
+    for i in range(N):
+        h1, l1 = g5.eval(g["x"][i:i + 1], pos[i:i + 1], 0, V)
+        check_5(h1[0], l1[0], i)
+    g5.close()
+
+
+def test_codec_vs_transformers_code2wav_fixture(gpu):
+    """ORACLE-FREE: csrc/codec.hip (RVQ sum, sliding-window transformer, ConvNeXt up-sampling, SnakeBeta / transposed-conv / residual-unit blocks, output
+    conv) on tests/golden/code2wav_tf.gguf against the waveform the `transformers` Qwen3OmniMoeCode2Wav computed for the same codes and weights
+    (tests/golden/make_code2wav_fixture.py; the public analogue of qwen3_tts_decoder.onnx, /root/reference/src/models/onnx.rs:342-458).  Streamed in
+    4-frame chunks like engine.rs:505-541, and once more through the grouped path; compared modulo the documented transposed-conv trim (a 45-sample
+    shift, left edge skipped).  PCM bar of north_star: 1e-4 RMS."""
+    from test_golden_cpu import C2W_EXP, C2W_GGUF, code2wav_compare
+    g = np.load(C2W_EXP)
+    codes = g["codes"]
+    d = gpu.Decoder(C2W_GGUF, n_streams=3, max_frames=4, max_group=2)
+    d.reset(1)
+    ours = np.concatenate([d.decode(codes[o:o + 4], stream=1, is_last=o + 4 >= codes.shape[0]).copy() for o in range(0, codes.shape[0], 4)])
+    assert ours.size == codes.shape[0] * d.spf
+    rms, mx = code2wav_compare(ours, g)
+    assert rms < 1e-5 and mx < 1e-4, (rms, mx)
+    d.reset(0); d.reset(2)
+    grp = np.concatenate([d.decode_group([2, 0], np.stack([codes[o:o + 4], codes[o:o + 4]])) for o in range(0, codes.shape[0], 4)], axis=1)
+    for row in grp:
+        rms, mx = code2wav_compare(row, g)
+        assert rms < 1e-5 and mx < 1e-4, (rms, mx)
+    d.close()
 
 
 def test_transformer_fused_path_bit_exact(gpu, oracle, tiny_model):
