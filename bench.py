@@ -91,6 +91,24 @@ def reduce_over_ranks(dist, torch, dev, audio_s, elapsed):
     return float(a.item()), float(t.item())
 
 
+def describe_ranks(dist, torch, dev, audio_s, elapsed, device_name):
+    """What a multi-GPU line must say about itself (nobody can launch N > 1 on this pool but the driver): per-rank audio seconds and elapsed
+    times (all_gather), the world size the COLLECTIVE saw (an all_reduce of ones -- not the launcher's environment), the backend, and every
+    rank's device name.  Single process: the same keys with one entry."""
+    if dist is None:
+        return {"per_rank_audio_s": [audio_s], "per_rank_elapsed_s": [elapsed], "rccl_world": 1, "backend": None, "devices": [device_name]}
+    world = dist.get_world_size()
+    mine = torch.tensor([audio_s, elapsed], dtype=torch.float64, device=dev)
+    allv = [torch.zeros(2, dtype=torch.float64, device=dev) for _ in range(world)]
+    dist.all_gather(allv, mine)
+    ones = torch.ones(1, dtype=torch.float64, device=dev)
+    dist.all_reduce(ones, op=dist.ReduceOp.SUM)
+    names = [None] * world
+    dist.all_gather_object(names, device_name)
+    return {"per_rank_audio_s": [float(v[0].item()) for v in allv], "per_rank_elapsed_s": [float(v[1].item()) for v in allv],
+            "rccl_world": int(round(float(ones.item()))), "backend": dist.get_backend(), "devices": names}
+
+
 def ensure_model(model_dir, quant):
     marker = os.path.join(model_dir, ".complete_" + quant)
     if os.path.exists(marker):
@@ -137,8 +155,11 @@ def host_cpu_info():
 def cpu_baseline(model_dir, quant_dir, prompt, codec_path):
     """The CPU restatement (oracle/, kind "port") of the same single-utterance loop, timed on this box's host cores the way the reference
     threads it: talker + predictor on 4 threads (llama.cpp thread cap, /root/reference/src/models/llama/mod.rs:420-428), the codec decoder
-    on its own thread (engine.rs:495) -- so the AR loop and the decoder overlap and the utterance takes max(AR, codec) -- plus an
-    all-usable-cores figure.  BOUNDED sample (a few prefill tokens + frames), extrapolated to the 43-row / 128-frame utterance of C2."""
+    on its own thread (engine.rs:495) with a team of its own -- so the AR loop and the decoder overlap and the utterance takes
+    max(AR, codec).  Headline = 4 + 4 threads; `all_cores` = every usable core for the AR loop and then for the codec (no overlap assumed:
+    both want all of them).  The codec is threaded over (channel, time) pairs, so it scales with the cores it is given and the figures are
+    AR-bound like the reference's own (README.md:31-32).  BOUNDED sample (a few prefill tokens + frames), extrapolated to the 43-row /
+    128-frame utterance of C2."""
     sys.path.insert(0, os.path.join(ROOT, "tests"))
     import q3oracle as O
     info = host_cpu_info()
@@ -160,6 +181,7 @@ def cpu_baseline(model_dir, quant_dir, prompt, codec_path):
     def codec_rate(threads):
         if not (codec_path and os.path.exists(codec_path)):
             return None
+        O.set_threads(threads)
         oc = O.Codec(codec_path)
         oc.reset()
         rng = np.random.default_rng(3)
@@ -171,24 +193,30 @@ def cpu_baseline(model_dir, quant_dir, prompt, codec_path):
         return t
 
     t_pre4, t_frame4 = ar_rate(4)
-    t_codec = codec_rate(4)
+    t_codec4 = codec_rate(4)
     ar_total = t_pre4 * prompt.shape[0] + t_frame4 * frames
-    codec_total = (t_codec or 0.0) * frames
-    total4 = max(ar_total, codec_total) + (4 * (t_codec or 0.0))   # overlapped threads + the last chunk's decode after the loop
-    out.update({"value": frames * FRAME_SEC / total4, "cores": 4 + (1 if t_codec else 0), "rtf": total4 / (frames * FRAME_SEC)})
+    codec_total = (t_codec4 or 0.0) * frames
+    total4 = max(ar_total, codec_total) + (4 * (t_codec4 or 0.0))   # overlapped threads + the last chunk's decode after the loop
+    out.update({"value": frames * FRAME_SEC / total4, "cores": 4 + (4 if t_codec4 else 0), "rtf": total4 / (frames * FRAME_SEC),
+                "s_per_prefill_token": t_pre4, "s_per_frame_ar": t_frame4, "s_per_frame_codec": t_codec4,
+                "bound_by": "codec thread" if codec_total > ar_total else "AR loop"})
     allc = max(1, min(int(info["usable_cpus"] or 4), 16))   # 16 = a one-GPU box's CPU share on this pool
     extra = ""
     if allc > 4:
         t_preA, t_frameA = ar_rate(allc)
-        totalA = max(t_preA * prompt.shape[0] + t_frameA * frames, codec_total) + 4 * (t_codec or 0.0)
+        t_codecA = codec_rate(allc)
+        totalA = t_preA * prompt.shape[0] + (t_frameA + (t_codecA or 0.0)) * frames
         out["all_cores"] = {"value": frames * FRAME_SEC / totalA, "cores": allc, "rtf": totalA / (frames * FRAME_SEC),
-                            "s_per_prefill_token": t_preA, "s_per_frame": t_frameA}
+                            "s_per_prefill_token": t_preA, "s_per_frame_ar": t_frameA, "s_per_frame_codec": t_codecA,
+                            "note": "AR loop and codec both on every core, one after the other (no overlap assumed)"}
         extra = "; all-cores run: %d threads" % allc
+    out["reference_published"] = {"rtf_cpu_q8_0": 1.866, "rtf_cpu_q5_k_m": 1.677, "hardware": "Intel i9-13980HX, llama.cpp b8123 + onnxruntime 1.24.2, real weights",
+                                  "source": "reference README.md:31-32 (context only: different CPU, weights and utterance)"}
     out["sample"] = ("oracle single-utterance loop, config-C2 shape: %d prefill tokens + %d AR frames timed on 4 threads (%.3f s/token, "
-                     "%.3f s/frame)%s, codec %s; utterance = max(AR, codec thread) extrapolated to %d prompt rows + %d frames%s"
+                     "%.3f s/frame)%s; utterance = max(AR, codec thread) extrapolated to %d prompt rows + %d frames%s"
                      % (n_pre, n_fr, t_pre4, t_frame4,
-                        "" if t_codec is None else " + one 4-frame codec chunk (%.3f s/frame)" % t_codec,
-                        "on its own thread" if t_codec is not None else "absent", prompt.shape[0], frames, extra))
+                        ", codec absent" if t_codec4 is None else " + one 4-frame codec chunk on a 4-thread team of its own (%.3f s/frame)" % t_codec4,
+                        prompt.shape[0], frames, extra))
     return out
 
 
@@ -200,8 +228,21 @@ def load_traffic(kernel_key):
         tab = json.load(open(path))
     except (OSError, ValueError):
         return None
-    ent = tab.get(kernel_key) or next((v for k, v in tab.items() if k.startswith(kernel_key.rstrip(">"))), None)  # template arguments may follow
+    ent = tab.get(kernel_key) or next((v for k, v in tab.items() if k != "_meta" and k.startswith(kernel_key.rstrip(">"))), None)  # template arguments may follow
     return float(ent["read_bytes"] + ent.get("write_bytes", 0.0)) if ent else None
+
+
+def traffic_source(kernel_key):
+    """`roofline.traffic` is NOT measured by this run (PMC counters need separate rocprofv3 --pmc passes): it is read from the tracked summary of the
+    builder's last PMC pass; say so, and say which commit's kernel it belongs to, so a stale figure is visible as stale"""
+    path = os.path.join(ROOT, "profiles", "hbm_traffic_latest.json")
+    try:
+        tab = json.load(open(path))
+    except (OSError, ValueError):
+        return None
+    meta = tab.get("_meta", {})
+    return "tracked file profiles/hbm_traffic_latest.json (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, %s); not collected by this run" % (
+        meta.get("collected", "round 2, kernel k_gemm_q8_mfma<true> before the round-3 one-tile kernel"))
 
 
 class StubEngine:
@@ -351,6 +392,8 @@ def main(argv=None):
     elapsed_local = time.perf_counter() - t0
     audio_local = last_run["frames"] * FRAME_SEC
     audio_s, elapsed = reduce_over_ranks(dist, torch, dev, audio_local, elapsed_local)
+    ranks_info = describe_ranks(dist, torch, dev, audio_local, elapsed_local,
+                                "cpu (stub engine)" if stub else torch.cuda.get_device_name(local_rank))
     st = eng.stats()
     log("timed region done: %.3f s (this rank %.3f s, %.1f audio-s)" % (elapsed, elapsed_local, audio_local))
     n_frames = res["codes"].shape[0]
@@ -375,6 +418,7 @@ def main(argv=None):
                        "mean_graph_width": st["slot_frames"] / max(st["graph_frames"], 1),
                        "codec_in_timed_region": bool(have_codec), "parallelism": "request-sharded x%d" % world},
             "audio_s_total": audio_s, "elapsed_s": elapsed,
+            "ranks": ranks_info,   # per-rank audio / elapsed, the world size the collective saw, backend, device names
             "batch_rtf": elapsed / audio_s,
             "batch_first_chunk_ms_p50": statistics.median([v for v in timed_first_chunk if v > 0] or [0.0]),
             "batch_decode_ms_per_step_frame": frame_ms,
@@ -414,12 +458,14 @@ def main(argv=None):
             if args.quant == "q5_k_m":
                 kname, kkey = "q3::k_gemm_kq_mfma<GU, Q5_K> (talker gate/up GEMM on packed K-quant planes + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_kq_mfma<true"
             else:
-                kname, kkey = "q3::k_gemm_q8_mfma<GU> (talker gate/up GEMM + SwiGLU + quant, %d tokens per launch)" % ntok, "k_gemm_q8_mfma<true>"
+                one_tile = ntok <= 128   # every workgroup owns one 32-token tile: the latency-tuned kernel (csrc/kernels.hip launch_gateup_mfma)
+                kname = "q3::%s<GU> (talker gate/up GEMM + SwiGLU + quant, %d tokens per launch)" % ("k_gemm_q8_tile1" if one_tile else "k_gemm_q8_mfma", ntok)
+                kkey = "k_gemm_q8_tile1<true>" if one_tile else "k_gemm_q8_mfma<true>"
         # dominant kernel by algorithmic bytes AND by share of the batched step: the talker's gate/up launch (12288 rows x 2048 x 1.0625 B
         # = 26.7 MB of Q8_0 weights per launch, 28 launches per frame step)
         roof = {"bound": "hbm", "kernel": "%s; %d launches" % (kname, si["gu_launches"]),
                 "achieved": gu_gbs, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gu_gbs / HBM_PEAK_GBS,
-                "avg_launch_us": gu_us, "bytes_per_launch": gu_bpl, "traffic": load_traffic(kkey),
+                "avg_launch_us": gu_us, "bytes_per_launch": gu_bpl, "traffic": load_traffic(kkey), "traffic_source": traffic_source(kkey),
                 "method": "HIP-event pair on the engine's stream around every launch in an eager replay of the same K steps (adds ~2 us over rocprofv3's kernel time)",
                 "family_all_weight_streaming_launches": {"achieved": fam_gbs, "frac": fam_gbs / HBM_PEAK_GBS, "launches": fam_n,
                                                          "avg_launch_us": 1e3 * fam_ms / max(fam_n, 1), "bytes_per_launch": fam_bytes / max(fam_n, 1)}}

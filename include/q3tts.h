@@ -135,6 +135,14 @@ void q3tts_group_destroy(q3tts_group* g);
 int32_t q3tts_group_size(q3tts_group* g);
 q3tts_engine* q3tts_group_engine(q3tts_group* g, int32_t i);   /* borrowed: stats, assets, per-engine calls */
 int32_t q3tts_group_uses_rccl(q3tts_group* g);                 /* 1: registrations go through ncclBroadcast, 0: peer copies */
+/* What the group's one exchange step actually runs on, so a multi-GPU harness can ASSERT "RCCL, N ranks" instead of assuming it: rccl_ranks = size of
+ * the ncclCommInitAll communicator set (0 = peer copies: one device, a device listed twice, or librccl absent), and how many registrations took
+ * which path so far.  The first registration also prints one line to stderr naming the path. */
+typedef struct q3tts_group_info_t {
+    int32_t n_devices, rccl_loaded, rccl_ranks, distinct_devices;
+    int64_t registrations_rccl, registrations_peer_copy;
+} q3tts_group_info_t;
+int q3tts_group_info(q3tts_group* g, q3tts_group_info_t* out);
 int q3tts_group_voice_register(q3tts_group* g, const float* spk_emb2048, const int32_t* ref_codes, int32_t n_ref_codes,
                                const int32_t* ref_text_ids, int32_t n_ref_text, int32_t* voice_id);
 int q3tts_group_submit(q3tts_group* g, const q3tts_request* r, int32_t want_pcm, int64_t* req_id);

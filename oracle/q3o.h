@@ -162,6 +162,7 @@ q3o_codec* q3o_codec_load(const char* path, char* err, size_t errlen);
 void q3o_codec_free(q3o_codec* c);
 void q3o_codec_reset(q3o_codec* c);
 int q3o_codec_samples_per_frame(const q3o_codec* c);
+void q3o_set_threads(int n); /* OpenMP team size for the calling thread's following parallel regions */
 /* streaming decode of n_frames frames (codes [n_frames][16]); returns samples written */
 int q3o_codec_decode(q3o_codec* c, const int64_t* codes, int n_frames, int is_last, float* pcm, int max_samples);
 

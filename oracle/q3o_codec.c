@@ -16,6 +16,9 @@
  * Accumulation is in double (this is a float-tolerance oracle: PCM within 1e-4 RMS).
  */
 #include "q3o.h"
+#ifdef _OPENMP
+#include <omp.h>
+#endif
 #include <stdio.h>
 #include <stdlib.h>
 #include <stdarg.h>
@@ -92,10 +95,12 @@ static void conv_run(conv_t* cv, const float* in, int T, float* out) {
         memcpy(ext + (size_t)c * W + H, in + (size_t)c * T, (size_t)T * 4);
     }
     const int cpg_in = cv->cin / cv->groups, cpg_out = cv->cout / cv->groups;
-#pragma omp parallel for schedule(static)
+    /* (channel, time) pairs are independent sums: collapsing both loops keeps every core busy in the narrow stages at the end of the stack
+       (96 ... 1 output channels over tens of thousands of samples) without changing a single result */
+#pragma omp parallel for collapse(2) schedule(static)
     for (int co = 0; co < cv->cout; co++) {
-        int g = co / cpg_out;
         for (int t = 0; t < T; t++) {
+            const int g = co / cpg_out;
             double acc = cv->b ? cv->b[co] : 0.0;
             for (int ci = 0; ci < cpg_in; ci++) {
                 const float* x = ext + (size_t)(g * cpg_in + ci) * W + t; /* x[t + j*dil] == input time t-(k-1-j)*dil */
@@ -116,7 +121,7 @@ static void convt_run(convt_t* ct, const float* in, int T, float* out) {
         memcpy(ext + (size_t)c * W, ct->prev + (size_t)c * P, (size_t)P * 4);
         memcpy(ext + (size_t)c * W + P, in + (size_t)c * T, (size_t)T * 4);
     }
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
     for (int co = 0; co < ct->cout; co++) {
         for (int n = 0; n < T * s; n++) {
             double acc = ct->b ? ct->b[co] : 0.0;
@@ -134,6 +139,7 @@ static void convt_run(convt_t* ct, const float* in, int T, float* out) {
     free(ext);
 }
 static void snake_run(const snake_t* s, float* x, int T) {
+#pragma omp parallel for collapse(2) schedule(static)
     for (int c = 0; c < s->c; c++)
         for (int t = 0; t < T; t++) {
             float v = x[(size_t)c * T + t];
@@ -143,7 +149,7 @@ static void snake_run(const snake_t* s, float* x, int T) {
 }
 /* y[n][t] = sum_k W[n][k] x[k][t] (+b[n]) ; x,y channel-major [C][T] */
 static void linear_ct(const float* W, const float* b, int n_out, int n_in, const float* x, int T, float* y) {
-#pragma omp parallel for schedule(static)
+#pragma omp parallel for collapse(2) schedule(static)
     for (int n = 0; n < n_out; n++)
         for (int t = 0; t < T; t++) {
             double acc = b ? b[n] : 0.0;
@@ -247,6 +253,15 @@ void q3o_codec_reset(q3o_codec* c) { /* AudioDecoder::create_state, onnx.rs:474-
     c->kv_len = 0; c->n_seen = 0;
     for (int i = 0; i < c->n_up; i++) { convt_reset(&c->up[i].ct); conv_reset(&c->up[i].dw); }
     for (int b = 0; b < c->n_dec; b++) { convt_reset(&c->dec[b].ct); for (int u = 0; u < 3; u++) { conv_reset(&c->dec[b].ru[u].c1); conv_reset(&c->dec[b].ru[u].c2); } }
+}
+/* OpenMP team size of the calling thread's next parallel regions (the codec thread of engine.rs:495 runs with the library's default team;
+   bench.py's cpu_baseline leg sets it explicitly so that the 4-thread and the all-cores figures are what they say) */
+void q3o_set_threads(int n) {
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
 }
 int q3o_codec_samples_per_frame(const q3o_codec* c) {
     int s = 1;

@@ -131,6 +131,9 @@ struct q3tts_group {
     std::atomic<uint64_t> rr{0};
     std::mutex mu; // serialises registrations
     bool started = false;
+    bool distinct = true;                 // every listed device is a different one
+    int64_t n_reg_rccl = 0, n_reg_peer = 0; // registrations by the path their bytes took (q3tts_group_info)
+    bool path_logged = false;
     ~q3tts_group() {
         for (auto c : comm) if (c) (void)rccl().CommDestroy(c);
         for (auto& s : slot) s.release();
@@ -159,6 +162,7 @@ int q3tts_group_create(const q3tts_engine_params* p, const int32_t* device_ids, 
         for (int j = 0; j < i; j++) if (device_ids[j] == device_ids[i]) distinct = false;
     }
     std::unique_ptr<q3tts_group> g(new q3tts_group());
+    g->distinct = distinct;
     g->eng.assign(n_dev, nullptr);
     g->slot.resize(n_dev);
     for (int i = 0; i < n_dev; i++) {
@@ -190,6 +194,19 @@ void q3tts_group_destroy(q3tts_group* g) { delete g; }
 int32_t q3tts_group_size(q3tts_group* g) { return g ? (int32_t)g->eng.size() : 0; }
 q3tts_engine* q3tts_group_engine(q3tts_group* g, int32_t i) { return (g && i >= 0 && i < (int)g->eng.size()) ? g->eng[i] : nullptr; }
 int32_t q3tts_group_uses_rccl(q3tts_group* g) { return g && !g->comm.empty() ? 1 : 0; }
+int q3tts_group_info(q3tts_group* g, q3tts_group_info_t* out) {
+    Q3_API_BEGIN
+    Q3_CHECK(g && out, "null argument");
+    std::lock_guard<std::mutex> lk(g->mu);
+    out->n_devices = (int32_t)g->eng.size();
+    out->rccl_loaded = rccl().ok() ? 1 : 0;
+    out->rccl_ranks = (int32_t)g->comm.size();
+    out->distinct_devices = g->distinct ? 1 : 0;
+    out->registrations_rccl = g->n_reg_rccl;
+    out->registrations_peer_copy = g->n_reg_peer;
+    return Q3TTS_OK;
+    Q3_API_END(Q3TTS_ERR)
+}
 
 int q3tts_group_voice_register(q3tts_group* g, const float* spk, const int32_t* ref_codes, int32_t n_ref_codes, const int32_t* ref_text,
                                int32_t n_ref_text, int32_t* voice_id) {
@@ -206,6 +223,13 @@ int q3tts_group_voice_register(q3tts_group* g, const float* spk, const int32_t* 
     Q3_HIP(hipMemcpyAsync(s0.d_buf, s0.h_buf, pay.size(), hipMemcpyHostToDevice, s0.st));
     Q3_HIP(hipStreamSynchronize(s0.st));
     // ... and the bytes travel device to device
+    if (!g->path_logged) { // once per group: which path registrations take (a multi-GPU run must be able to show "RCCL, N ranks", not assume it)
+        g->path_logged = true;
+        std::fprintf(stderr, "[q3tts group] voice registrations: %s over %d device(s)%s\n", !g->comm.empty() ? "ncclBroadcast (RCCL communicators from ncclCommInitAll)" :
+                     n > 1 ? "hipMemcpyPeerAsync (no RCCL communicators)" : "single device, no exchange", n,
+                     g->comm.empty() && n > 1 ? (!g->distinct ? " -- a device is listed twice" : !rccl().ok() ? " -- librccl not loaded" : "") : "");
+    }
+    if (!g->comm.empty()) g->n_reg_rccl++; else if (n > 1) g->n_reg_peer++;
     if (!g->comm.empty()) {
         nccl_check(rccl().GroupStart(), "ncclGroupStart");
         for (int i = 0; i < n; i++) {

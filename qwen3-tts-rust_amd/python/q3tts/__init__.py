@@ -72,7 +72,7 @@ SYMBOLS = [
     "q3tts_onnx_node_attr_ints", "q3tts_onnx_node_attr_float", "q3tts_onnx_initializer", "q3tts_onnx_op_kernel", "q3tts_onnx_decoder_contract",
     "q3tts_onnx_session_open", "q3tts_onnx_session_close", "q3tts_onnx_session_unsupported", "q3tts_onnx_session_set_input", "q3tts_onnx_session_run",
     "q3tts_onnx_session_output_info", "q3tts_onnx_session_output", "q3tts_onnx_session_launches", "q3tts_onnx_op_executable",
-    "q3tts_text_nfc", "q3tts_op_gemv_kq", "q3tts_op_gateup_kq", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_fetch", "q3tts_onnx_decoder_decode",
+    "q3tts_text_nfc", "q3tts_op_gemv_kq", "q3tts_op_gateup_kq", "q3tts_onnx_decoder_open", "q3tts_onnx_decoder_close", "q3tts_onnx_decoder_reset", "q3tts_onnx_decoder_fetch", "q3tts_group_info", "q3tts_onnx_decoder_decode",
     "q3tts_decoder_state_floats", "q3tts_decoder_state_export", "q3tts_decoder_state_import", "q3tts_decoder_state_entry",
     "q3tts_tokenizer_open", "q3tts_tokenizer_close", "q3tts_tokenizer_encode", "q3tts_tokenizer_decode", "q3tts_tokenizer_vocab_size",
 ]

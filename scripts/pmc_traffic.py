@@ -19,8 +19,8 @@ def load(path):
 fetch, write = load(sys.argv[1]), load(sys.argv[2])
 tag = sys.argv[5] if len(sys.argv) > 5 else "r02"
 # algorithmic bytes per launch of the weight-streaming launches of Q3TTS-1.7B-synth Q8_0 (rows x K x 1.0625 B), keyed by (kernel prefix, grid threads)
-ALG = {("k_gemm_q8_mfma<true", "196608"): 12288 * 2048 * 1.0625, ("k_gemm_q8_mfma2<true", "196608"): 12288 * 2048 * 1.0625,
-       ("k_gemm_q8_mfma2<true", "98304"): 12288 * 2048 * 1.0625,
+ALG = {("k_gemm_q8_mfma<true", "196608"): 12288 * 2048 * 1.0625, ("k_gemm_q8_tile1<true", "196608"): 12288 * 2048 * 1.0625,
+       ("k_gemm_q8_tile1<true", "49152"): 6144 * 1024 * 1.0625,
        ("k_gateup_swiglu<1, 8", "98304"): 12288 * 2048 * 1.0625, ("k_gateup_swiglu<1, 4", "24576"): 6144 * 1024 * 1.0625}
 rows, table = [], {}
 for key, v in sorted(fetch.items(), key=lambda kv: -sum(kv[1]))[:24]:
@@ -32,6 +32,7 @@ for key, v in sorted(fetch.items(), key=lambda kv: -sum(kv[1]))[:24]:
     if alg:
         name = key[0].split("<")[0] + ("<true>" if "<true" in key[0] else "<" + key[0].split("<", 1)[1] if "<" in key[0] else "")
         table.setdefault(name if "gemm" in name else key[0], {"read_bytes": rd, "write_bytes": wr, "launches": len(v), "grid_threads": key[1], "algorithmic_bytes": alg})
+table["_meta"] = {"collected": "%s, this commit's kernels" % tag}
 json.dump(table, open(sys.argv[3], "w"), indent=1)
 lines = ["# HBM traffic per launch from rocprofv3 PMC passes (%s)" % tag, "",
          "    rocprofv3 --kernel-trace --pmc FETCH_SIZE --output-format csv -- python3 bench.py --steps 4 --warmup 1 --no-cpu-baseline --no-c2-leg",

@@ -35,6 +35,20 @@ int main(int argc, char** argv) {
     CHECK(q3tts_group_voice_register(g, spk.data(), nullptr, 0, nullptr, 0, &preset));
     CHECK(q3tts_group_voice_register(g, spk.data(), ref_codes.data(), (int32_t)ref_codes.size(), ref_text.data(), (int32_t)ref_text.size(), &clone));
     if (preset != 0 || clone != 1) { fprintf(stderr, "voice ids %d %d\n", preset, clone); return 1; }
+    {   // the exchange step must be able to say what it ran on: distinct devices + librccl => "RCCL, n ranks", and both registrations counted there;
+        // one device / a device listed twice => peer copies.  A multi-GPU box that silently fell back to copies fails HERE.
+        q3tts_group_info_t gi;
+        CHECK(q3tts_group_info(g, &gi));
+        const bool distinct = n <= n_vis;
+        const bool expect_rccl = n > 1 && distinct && gi.rccl_loaded;
+        printf("GROUP_INFO devices %d rccl_loaded %d rccl_ranks %d distinct %d reg_rccl %lld reg_peer %lld\n", gi.n_devices, gi.rccl_loaded, gi.rccl_ranks,
+               gi.distinct_devices, (long long)gi.registrations_rccl, (long long)gi.registrations_peer_copy);
+        if (gi.n_devices != n || gi.distinct_devices != (distinct ? 1 : 0) || gi.rccl_ranks != (expect_rccl ? n : 0) ||
+            gi.registrations_rccl != (expect_rccl ? 2 : 0) || gi.registrations_peer_copy != ((!expect_rccl && n > 1) ? 2 : 0)) {
+            fprintf(stderr, "group info does not match the path the registrations must have taken\n");
+            return 1;
+        }
+    }
     CHECK(q3tts_group_start(g));
     q3tts_sampler_config sc;
     q3tts_sampler_config_default(&sc);

@@ -259,6 +259,11 @@ class Codec:
         return pcm[:n]
 
 
+def set_threads(n):
+    """OpenMP team size of the calling thread's following oracle calls (codec, mel); Engine / Model take theirs as a constructor argument"""
+    lib().q3o_set_threads(int(n))
+
+
 def mel(audio):
     audio = np.ascontiguousarray(audio, np.float32)
     n = lib().q3o_mel(_p(audio), audio.size, None)

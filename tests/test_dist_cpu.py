@@ -77,6 +77,12 @@ def test_bench_launcher_and_rank_aggregation_world2():
     assert abs(out["audio_s_total"] - 2 * frames * 0.08) < 1e-9
     assert abs(out["value"] - out["audio_s_total"] / out["elapsed_s"]) < 1e-9
     assert out["elapsed_s"] >= 0.04          # rank 1's stub sleeps 40 ms: the MAX over ranks, not rank 0's 20 ms
+    # the line describes its own ranks: what every rank generated and took, the world size the collective itself saw, backend, devices
+    rk = out["ranks"]
+    assert rk["rccl_world"] == 2 and rk["backend"] == "gloo" and len(rk["devices"]) == 2
+    assert len(rk["per_rank_audio_s"]) == 2 and all(abs(a - frames * 0.08) < 1e-9 for a in rk["per_rank_audio_s"])
+    assert abs(sum(rk["per_rank_audio_s"]) - out["audio_s_total"]) < 1e-9 and abs(max(rk["per_rank_elapsed_s"]) - out["elapsed_s"]) < 1e-9
+    assert rk["per_rank_elapsed_s"][1] > rk["per_rank_elapsed_s"][0] * 0.9   # rank 1's stub is the slower one (40 vs 20 ms of sleep)
 
 
 def test_bench_rejects_mismatched_world():
