@@ -212,6 +212,45 @@ Q3_HD int q3_mrope_stream(int i, const int32_t sec[4]) {
     return 3;
 }
 
+/* ---------------- "ggml-CPU" arithmetic mode (opt-in, Q3_SPEC=ggml) ----------------
+ * expf as glibc's generic (non-FMA) float routine computes it [EXT: sysdeps/ieee754/flt-32/e_expf.c + exp2f_data, N = 32]: a 32-entry table of
+ * 2^(i/32) and a degree-3 polynomial, all in double, one rounding to float at the end.  Restated so that the oracle's ggml mode and the HIP
+ * ggml-mode kernels share ONE definition (libm's expf differs between hosts: FMA builds contract differently); on the build container's glibc the
+ * two agree on every one of 200 000 random arguments (table recomputed with exact integer arithmetic, tests/test_ggml_mode_cpu.py keeps checking). */
+Q3_HD float q3_expf_ggml(float x) {
+    static const uint64_t T[32] = {
+        0x3ff0000000000000ull, 0x3fefd9b0d3158574ull, 0x3fefb5586cf9890full, 0x3fef9301d0125b51ull, 0x3fef72b83c7d517bull, 0x3fef54873168b9aaull,
+        0x3fef387a6e756238ull, 0x3fef1e9df51fdee1ull, 0x3fef06fe0a31b715ull, 0x3feef1a7373aa9cbull, 0x3feedea64c123422ull, 0x3feece086061892dull,
+        0x3feebfdad5362a27ull, 0x3feeb42b569d4f82ull, 0x3feeab07dd485429ull, 0x3feea47eb03a5585ull, 0x3feea09e667f3bcdull, 0x3fee9f75e8ec5f74ull,
+        0x3feea11473eb0187ull, 0x3feea589994cce13ull, 0x3feeace5422aa0dbull, 0x3feeb737b0cdc5e5ull, 0x3feec49182a3f090ull, 0x3feed503b23e255dull,
+        0x3feee89f995ad3adull, 0x3feeff76f2fb5e47ull, 0x3fef199bdd85529cull, 0x3fef3720dcef9069ull, 0x3fef5818dcfba487ull, 0x3fef7c97337b9b5full,
+        0x3fefa4afa2a490daull, 0x3fefd0765b6e4540ull};
+    if (x != x) return x;
+    if (x > 88.72283172607421875f) return q3_bits_f32(0x7F800000u);
+    if (x < -103.97208404541015625f) return 0.0f;
+    const double InvLn2N = 0x1.71547652b82fep+0 * 32.0, Shift = 0x1.8p+52;
+    const double C0 = 0x1.c6af84b912394p-5 / 32.0 / 32.0 / 32.0, C1 = 0x1.ebfce50fac4f3p-3 / 32.0 / 32.0, C2 = 0x1.62e42ff0c52d6p-1 / 32.0;
+    const double z = InvLn2N * (double)x;
+    double kd = z + Shift;
+    uint64_t ki; memcpy(&ki, &kd, 8);
+    kd = kd - Shift;
+    const double r = z - kd;
+    uint64_t t = T[ki % 32] + (ki << (52 - 5));
+    double s; memcpy(&s, &t, 8);
+    const double zz = C0 * r + C1;
+    const double r2 = r * r;
+    double y = C2 * r + 1.0;
+    y = zz * r2 + y;
+    y = y * s;
+    return (float)y;
+}
+/* ggml-quants.c nearest_int: magic-number rounding (half to even), |v| <= 4194303 */
+Q3_HD int q3_nearest_int_ggml(float fval) {
+    float val = fval + 12582912.f;
+    int32_t i; memcpy(&i, &val, 4);
+    return (i & 0x007fffff) - 0x00400000;
+}
+
 /* ggml tensor types used by this engine (public GGUF spec [EXT]) */
 enum q3_ggml_type {
     Q3_T_F32 = 0, Q3_T_F16 = 1, Q3_T_Q8_0 = 8, Q3_T_Q5_K = 13, Q3_T_Q6_K = 14, Q3_T_BF16 = 30

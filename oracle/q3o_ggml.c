@@ -18,7 +18,8 @@
  *   - float weights: activations converted to the weight type (f16 / bf16) and products accumulated in double (ggml_vec_dot_f16 /
  *     _bf16 / _f32 generic forms use ggml_float = double);
  *   - RMSNorm: sum of squares accumulated in double (ggml_compute_forward_rms_norm_f32), scale = 1/sqrtf(mean + eps);
- *   - softmax / SiLU: libm expf, softmax sum in double (ggml_vec_soft_max_f32), SiLU x / (1 + expf(-x)).
+ *   - softmax / SiLU: expf as glibc's generic routine computes it (q3_expf_ggml in the spec header: ONE definition shared with the HIP ggml-mode kernels;
+ *     equal to this container's libm expf on every argument tried), softmax sum in double (ggml_vec_soft_max_f32), SiLU x / (1 + expf(-x)).
  * What stays on the spec: RoPE tables (double-precision cos/sin here; ggml iterates theta in f32), the f16 KV cache, attention's
  * score / PV summation order (llama.cpp's CPU flash-attention kernel blocks differently), residual adds.  SIMD builds of ggml (AVX2,
  * AVX-512, NEON) reorder the same sums again, so even this mode is "a llama.cpp", not "the llama.cpp" -- which is the point of
@@ -35,11 +36,7 @@ int q3o_arith_mode(void) {
 void q3o_set_arith_mode(int mode) { g_mode = mode ? 1 : 0; }
 
 static inline uint16_t ld16(const void* p) { uint16_t v; memcpy(&v, p, 2); return v; }
-static inline int nearest_int(float fval) { /* ggml-quants.c: magic-number rounding (half to even), |fval| <= 4194303 */
-    float val = fval + 12582912.f;
-    int i; memcpy(&i, &val, sizeof(int));
-    return (i & 0x007fffff) - 0x00400000;
-}
+static inline int nearest_int(float fval) { return q3_nearest_int_ggml(fval); }
 
 /* ---- quantize_row_q8_0_ref ---- */
 static void quant_q8_0_ggml(const float* x, int64_t k, int8_t* q, uint16_t* d16) {
@@ -210,7 +207,7 @@ void q3o_rmsnorm_ggml(const float* x, const float* g, int64_t d, float eps, floa
     for (int64_t i = 0; i < d; i++) y[i] = (x[i] * scale) * g[i];
 }
 void q3o_headnorm128_ggml(const float* x, const float* g, float eps, float* y) { q3o_rmsnorm_ggml(x, g, 128, eps, y); }
-float q3o_swiglu_ggml(float gt, float up) { return (gt / (1.0f + expf(-gt))) * up; }
+float q3o_swiglu_ggml(float gt, float up) { return (gt / (1.0f + q3_expf_ggml(-gt))) * up; }
 
 /* one query head against n cached f16 positions: scores in order, libm expf, softmax sum in double, PV in order */
 void q3o_attn_head_ggml(const float* q, const uint16_t* K, const uint16_t* V, size_t stride, int n, float* out) {
@@ -225,7 +222,7 @@ void q3o_attn_head_ggml(const float* q, const uint16_t* K, const uint16_t* V, si
         if (s[j] > mx) mx = s[j];
     }
     double sum = 0.0;
-    for (int j = 0; j < n; j++) { s[j] = expf(s[j] - mx); sum += (double)s[j]; }
+    for (int j = 0; j < n; j++) { s[j] = q3_expf_ggml(s[j] - mx); sum += (double)s[j]; }
     const float inv = (float)(1.0 / sum);
     for (int d = 0; d < 128; d++) {
         float acc = 0.0f;

@@ -9,7 +9,7 @@ FLAGS="${Q3_EXTRA_FLAGS:-} -mllvm -amdgpu-kernarg-preload-count=16 -O3 -std=c++1
 mkdir -p build
 OBJS=""
 PIDS=""
-for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/onnx_reader.cpp csrc/onnx_exec.hip csrc/tokenizer.cpp csrc/capi.cpp csrc/capi_ops.cpp csrc/group.cpp csrc/llama_shim.cpp; do
+for f in csrc/gguf.cpp csrc/host_logic.cpp csrc/kernels.hip csrc/kernels_fused.hip csrc/ggml_mode.hip csrc/sampler.hip csrc/transformer.cpp csrc/engine.cpp csrc/codec.hip csrc/mel.hip csrc/onnx_reader.cpp csrc/onnx_exec.hip csrc/tokenizer.cpp csrc/capi.cpp csrc/capi_ops.cpp csrc/group.cpp csrc/llama_shim.cpp; do
   [ -f "$f" ] || continue
   o=build/$(basename "$f").o
   if [ ! -f "$o" ] || [ "$f" -nt "$o" ] || [ -n "$(find csrc ../include -newer "$o" \( -name '*.h' \) -print -quit)" ]; then

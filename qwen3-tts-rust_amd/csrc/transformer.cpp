@@ -330,11 +330,24 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
         if (l == 0) layer_weight_bytes_ = L.wqkv.bytes() + L.wo.bytes() + L.wgu.bytes() + L.wdown.bytes();
         weight_bytes_ += L.wqkv.bytes() + L.wo.bytes() + L.wgu.bytes() + L.wdown.bytes();
     }
+    if (const char* e = std::getenv("Q3_SPEC")) ggml_mode_ = std::string(e) == "ggml";
+    if (ggml_mode_) {
+        Q3_CHECK(!float_mode_, "Q3_SPEC=ggml serves Q8_0 / Q5_K_M files (float-weight files have no ggml-mode kernels)");
+        gg_layers_.resize(hp_.n_layer);
+        for (int l = 0; l < hp_.n_layer; l++) {
+            const std::string p = "blk." + std::to_string(l) + ".";
+            GgLayer& G = gg_layers_[l];
+            G.wq = gg_load(g, p + "attn_q.weight", dq, d); G.wk = gg_load(g, p + "attn_k.weight", dkv, d); G.wv = gg_load(g, p + "attn_v.weight", dkv, d);
+            G.wo = gg_load(g, p + "attn_output.weight", d, dq);
+            G.gate = gg_load(g, p + "ffn_gate.weight", ff, d); G.up = gg_load(g, p + "ffn_up.weight", ff, d); G.down = gg_load(g, p + "ffn_down.weight", d, ff);
+        }
+    }
     output_norm_ = load_f32(g, "output_norm.weight", d);
     const GgufTensor& ot = g.need("output.weight");
     hp_.n_vocab = (int)ot.ne[1];
     if (float_mode_) { foutput_ = make_fmat(g, {"output.weight"}, d); fused = false; }
     else output_ = make_mat(g, {{"output.weight", 0}}, hp_.n_vocab, d);
+    if (ggml_mode_) gg_output_ = gg_load(g, "output.weight", hp_.n_vocab, d);
     // RoPE tables: same double-precision expressions as the oracle (spec S5)
     std::vector<float> c((size_t)n_ctx * 64), s((size_t)n_ctx * 64);
     for (int p = 0; p < n_ctx; p++)
@@ -353,7 +366,8 @@ Transformer::Transformer(const std::string& path, int n_ctx, int max_tok) : n_ct
 // second context over the same weights: see transformer.h
 Transformer::Transformer(const Transformer& o, int max_tok)
     : fused(o.fused), float_mode_(o.float_mode_), foutput_(o.foutput_), hp_(o.hp_), n_ctx_(o.n_ctx_), max_tok_(max_tok), layers_(o.layers_), output_(o.output_),
-      output_norm_(o.output_norm_), ws_(o.ws_), weight_bytes_(o.weight_bytes_), layer_weight_bytes_(o.layer_weight_bytes_), all_q8_(o.all_q8_) {
+      output_norm_(o.output_norm_), ws_(o.ws_), weight_bytes_(o.weight_bytes_), layer_weight_bytes_(o.layer_weight_bytes_), all_q8_(o.all_q8_),
+      ggml_mode_(o.ggml_mode_), gg_layers_(o.gg_layers_), gg_output_(o.gg_output_) {
     alloc_workspace();
 }
 
@@ -367,7 +381,58 @@ void Transformer::alloc_workspace() {
     qkv_.alloc(T * (dq + 2 * dkv)); qrot_.alloc(T * dq); gu_.alloc(T * 2 * ff);
     const size_t mx = (size_t)(d > dq ? d : dq);
     xq_.alloc(T * mx); xd_.alloc(T * mx / 32); aq_.alloc(T * dq); ad_.alloc(T * dq / 32); fq_.alloc(T * ff); fd_.alloc(T * ff / 32);
+    if (ggml_mode_) {
+        const size_t kmax = (size_t)std::max(std::max(d, dq), ff);
+        gg_q8_.alloc(T * kmax); gg_qk_.alloc(T * kmax); gg_d8_.alloc(T * kmax / 32); gg_dk_.alloc(T * kmax / 256); gg_bs_.alloc(T * kmax / 16);
+        gg_xn_.alloc(T * kmax); gg_att_.alloc(T * dq); gg_act_f_.alloc(T * ff); gg_scores_.alloc(T * hp_.n_head * (size_t)n_ctx_);
+        gg_act_ = GgAct{gg_q8_.p, gg_d8_.p, gg_qk_.p, gg_dk_.p, gg_bs_.p};
+    }
 }
+
+// ---- ggml-arithmetic mode (ggml_mode.hip): raw GGUF matrices, llama.cpp's portable arithmetic, bit-exact with oracle/q3o_ggml.c ----
+GgMat Transformer::gg_load(const Gguf& g, const std::string& name, int n_expect, int k_expect) {
+    const GgufTensor& t = g.need(name);
+    Q3_CHECK((int)t.ne[0] == k_expect && (int)t.ne[1] == n_expect, "ggml mode: shape of " + name);
+    Q3_CHECK(t.type == Q3_T_Q8_0 || t.type == Q3_T_Q5_K || t.type == Q3_T_Q6_K, "ggml mode: type of " + name);
+    GgMat m; m.type = t.type; m.n = n_expect; m.k = k_expect;
+    m.row_bytes = t.type == Q3_T_Q8_0 ? (size_t)(k_expect / 32) * 34 : t.type == Q3_T_Q5_K ? (size_t)(k_expect / 256) * 176 : (size_t)(k_expect / 256) * 210;
+    blobs_.emplace_back(m.row_bytes * (size_t)n_expect);
+    blobs_.back().upload(reinterpret_cast<const uint8_t*>(t.data), m.row_bytes * (size_t)n_expect);
+    m.p = blobs_.back().p;
+    return m;
+}
+void Transformer::gg_linear(hipStream_t st, const GgMat& w, int row0, int nrows, const float* x, float* out, int out_stride, int ntok) {
+    gg_quant(st, x, w.k, gg_act_, ntok);   // (ggml quantises the activations once per matmul call, to the weight type's vec_dot_type)
+    gg_matvec(st, w, row0, nrows, gg_act_, out, out_stride, ntok);
+}
+void Transformer::forward_ggml(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
+    const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff, qs = dq + 2 * dkv;
+    gg_load_rows(st, in.x, in.x_stride, in.idx, in.idx_stride, in.idx_keys, d, h_.p, ntok);
+    for (int l = 0; l < hp_.n_layer; l++) {
+        const Layer& L = layers_[l];
+        const GgLayer& G = gg_layers_[l];
+        gg_rmsnorm(st, h_.p, L.attn_norm, d, hp_.eps, gg_xn_.p, ntok);
+        gg_quant(st, gg_xn_.p, d, gg_act_, ntok);
+        gg_matvec(st, G.wq, 0, dq, gg_act_, qkv_.p, qs, ntok);
+        gg_matvec(st, G.wk, 0, dkv, gg_act_, qkv_.p + dq, qs, ntok);
+        gg_matvec(st, G.wv, 0, dkv, gg_act_, qkv_.p + dq + dkv, qs, ntok);
+        gg_qk_rope_append(st, qkv_.p, qs, hp_.n_head, hp_.n_kv, L.q_norm, L.k_norm, hp_.eps, rope_cos_.p, rope_sin_.p, n_ctx_, d_mrope_.p, tm, kv, l, ntok);
+        gg_attention(st, qkv_.p, qs, hp_.n_head, hp_.n_kv, tm, kv, l, gg_att_.p, gg_scores_.p, n_ctx_, ntok);
+        gg_linear(st, G.wo, 0, d, gg_att_.p, parts_o_.p, d, ntok);
+        gg_add(st, h_.p, parts_o_.p, (size_t)ntok * d);
+        gg_rmsnorm(st, h_.p, L.ffn_norm, d, hp_.eps, gg_xn_.p, ntok);
+        gg_quant(st, gg_xn_.p, d, gg_act_, ntok);
+        gg_matvec(st, G.gate, 0, ff, gg_act_, gu_.p, ff, ntok);
+        gg_matvec(st, G.up, 0, ff, gg_act_, gu_.p + (size_t)ntok * ff, ff, ntok);
+        gg_swiglu(st, gu_.p, gu_.p + (size_t)ntok * ff, gg_act_f_.p, (size_t)ntok * ff);
+        gg_linear(st, G.down, 0, d, gg_act_f_.p, parts_o_.p, d, ntok);
+        gg_add(st, h_.p, parts_o_.p, (size_t)ntok * d);
+    }
+    gg_rmsnorm(st, h_.p, output_norm_, d, hp_.eps, hid_.p, ntok);
+    if (hidden_out) launch_copy_f32(st, hid_.p, hidden_out, (size_t)ntok * d);
+    Q3_LAUNCH_CHECK();
+}
+
 
 void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, const int8_t* xq, const uint16_t* xd, float* out,
                        int out_stride, int ntok) {
@@ -379,6 +444,7 @@ void Transformer::gemv(hipStream_t st, const Q8Mat& w, int row0, int nrows, cons
 void Transformer::forward(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out) {
     Q3_CHECK(ntok >= 1 && ntok <= max_tok_, "ntok out of range");
     const int d = hp_.n_embd, dq = hp_.n_head * 128, dkv = hp_.n_kv * 128, ff = hp_.n_ff;
+    if (ggml_mode_) { last_fused_ = false; last_ntok_ = ntok; forward_ggml(st, in, ntok, tm, kv, hidden_out); return; }
     if (float_mode_) { last_fused_ = false; last_ntok_ = ntok; forward_float(st, in, ntok, tm, kv, hidden_out); return; }
     const bool use_fused = fused && ntok <= fused_max_tok_; // batched steps (ntok > 8) take the weight-stationary token-sweep GEMM path
     last_fused_ = use_fused; last_ntok_ = ntok;
@@ -533,6 +599,18 @@ void Transformer::head_impl(hipStream_t st, int tok0, int tok_count, int row0, i
                             const ArgmaxEpi* am, int nrows_valid, float* hidden_out) {
     const int d = hp_.n_embd;
     Q3_CHECK(row0 % 32 == 0 && (float_mode_ || row0 + nrows <= output_.Npad), "head row range");
+    if (ggml_mode_) { // final-norm hidden states are in hid_ (f32): quantise them for the output matrix's type, plain dots, optional argmax keys
+        if (hidden_out) launch_copy_f32(st, hid_.p + (size_t)tok0 * d, hidden_out, (size_t)tok_count * d);
+        if (nrows <= 0) return;
+        int nr = nrows;
+        if (row0 + nr > gg_output_.n) nr = gg_output_.n - row0;   // (callers pass row counts padded to 32)
+        float* dst = am ? big_logits_.p : logits;
+        const int ls = am ? nrows : logits_stride;
+        if (am && big_logits_.n < (size_t)tok_count * nrows) throw Error("head scratch too small");
+        gg_linear(st, gg_output_, row0, nr, hid_.p + (size_t)tok0 * d, dst, ls, tok_count);
+        if (am) launch_argmax_keys(st, big_logits_.p, nrows, std::min(nrows_valid > 0 ? nrows_valid : nrows, nr), am->mask_per_tok, am->keys, am->key_stride, tok_count);
+        return;
+    }
     if (last_fused_) {
         // final RMSNorm (+ last down-proj partials + residual) as the prologue of the output-matrix GEMV
         NormPro f{};

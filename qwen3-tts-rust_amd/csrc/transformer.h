@@ -4,6 +4,7 @@
 #include "q3_common.h"
 #include "gguf.h"
 #include "kernels.h"
+#include "ggml_mode.h"
 #include <map>
 #include <memory>
 
@@ -51,6 +52,10 @@ public:
     // which is fine for a model whose weights stay cache-resident, i.e. the code predictor)
     void set_fused_max_tokens(int n) { fused_max_tok_ = n; }
 
+    // Q3_SPEC=ggml at construction: the opt-in "ggml-CPU" arithmetic mode (ggml_mode.hip) -- every forward() / head() then runs llama.cpp's portable
+    // arithmetic as oracle/q3o_ggml.c restates it, on raw copies of the GGUF matrices; slow by design, bit-exact with that oracle
+    bool ggml_mode() const { return ggml_mode_; }
+
     LaunchTimer* timer = nullptr;    // optional per-GEMV-launch event timing (instrumented bench leg): whole GEMV family
     LaunchTimer* timer_gu = nullptr; // ... and the gate/up kernel alone (the dominant launch by bytes)
     // op-level access for parity tests
@@ -94,6 +99,16 @@ private:
     DevBuf<int8_t> xq_, aq_, fq_;
     DevBuf<uint16_t> xd_, ad_, fd_;
     int nparts_d_ = 1;
+    // ---- ggml-arithmetic mode ----
+    struct GgLayer { GgMat wq, wk, wv, wo, gate, up, down; };
+    bool ggml_mode_ = false;
+    std::vector<GgLayer> gg_layers_;
+    GgMat gg_output_;
+    GgMat gg_load(const Gguf& g, const std::string& name, int n_expect, int k_expect);
+    void forward_ggml(hipStream_t st, const Input& in, int ntok, const TokMeta& tm, const KvCache& kv, float* hidden_out);
+    void gg_linear(hipStream_t st, const GgMat& w, int row0, int nrows, const float* x, float* out, int out_stride, int ntok); // quantise x for w, then the dots
+    GgAct gg_act_{};
+    DevBuf<int8_t> gg_q8_, gg_qk_; DevBuf<uint16_t> gg_d8_; DevBuf<float> gg_dk_, gg_xn_, gg_att_, gg_scores_, gg_act_f_; DevBuf<int16_t> gg_bs_;
 };
 
 // standalone repack of host GGUF Q8_0 rows into a device Q8Mat (storage owns the memory); used by parity ops

@@ -180,3 +180,28 @@ def test_fullsize_q5_k_m_packed_planes_vs_oracle(gpu, oracle, full_model_q5, viv
     b8 = g8.bytes_per_step(1, 16)
     g8.close()
     assert b5 < 0.85 * b8, (b5, b8)
+
+
+def test_fullsize_ggml_mode_engine_matches_oracle(gpu, oracle, full_model, vivian):
+    """Q3_SPEC=ggml at the real dimensions (K = 2048 / 6144 talker, 1024 / 3072 predictor; 28 + 5 layers): the device's ggml-arithmetic path
+    (csrc/ggml_mode.hip) against oracle/q3o_ggml.c, codec tokens bit for bit -- SURVEY 8f row f-1, /root/reference/src/models/llama/mod.rs:442-451."""
+    old = os.environ.get("Q3_SPEC")
+    try:
+        os.environ["Q3_SPEC"] = "ggml"
+        oracle.set_arith_mode(1)
+        ge = gpu.Engine(full_model, "q8_0", max_batch=2, max_steps=16, load_codec=False)
+        rng = np.random.default_rng(321)
+        prompts = [ge.assets.build_core(rng.integers(0, 4000, 3 + i).astype(np.int32), lang_id=2055, spk_emb=vivian) for i in range(2)]
+        res = ge.generate_batch(prompts, max_steps=[3, 2], mask_eos=True)
+        ge.close()
+        oe = oracle.Engine(os.path.join(full_model, "gguf_q8_0"), None, 16)
+        for p, r, m in zip(prompts, res, (3, 2)):
+            oc, _ = oe.generate(p, max_steps=m, mask_eos=True)
+            assert np.array_equal(oc, r["codes"])
+        oe.close()
+    finally:
+        oracle.set_arith_mode(0)
+        if old is None:
+            os.environ.pop("Q3_SPEC", None)
+        else:
+            os.environ["Q3_SPEC"] = old
