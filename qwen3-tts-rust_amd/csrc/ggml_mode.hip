@@ -3,8 +3,8 @@
 // The reference's codec tokens come out of llama.cpp b8123's kernels (/root/reference/src/models/llama/mod.rs:442-451, version pin
 // src/download.rs:207-221), whose arithmetic differs from include/q3tts_spec.h's in ways that flip a few per cent of greedy tokens on
 // synthetic weights: activations quantised to Q8_K 256-blocks for K-quant rows, roundf for Q8_0 activations, block sums
-// accumulated without fma in ggml's order, sums of squares and softmax denominators in double.  oracle/q3o_ggml.c restates that arithmetic
-// on the CPU; these kernels restate the SAME arithmetic on the device, bit for bit (tests/test_gpu_parity.py::test_ggml_mode_engine_matches_oracle),
+// accumulated without fma in ggml's order, sums of squares and softmax denominators in double.  The test suite holds a CPU restatement of that
+// arithmetic; these kernels restate the SAME arithmetic on the device, bit for bit (tests/test_gpu_parity.py::test_ggml_mode_engine_matches_oracle),
 // so that the day llama.cpp b8123 and the real weights are at hand the GPU can be put beside the reference at all.
 //
 // This is a correctness path, not the product's fast path: one thread per (row, token tile) walks the GGUF blocks exactly as stored (a raw
@@ -208,7 +208,7 @@ __global__ void __launch_bounds__(64) k_gg_qk_rope_append(float* __restrict__ qk
         Vw[ps * 128 + lane] = f2h(vec[lane]); Vw[ps * 128 + lane + 64] = f2h(vec[lane + 64]);
     }
 }
-// one query head against its n cached f16 positions (q3o_attn_head_ggml): scores = plain dot in index order * 1/sqrt(128), expf, softmax sum in double
+// one query head against its n cached f16 positions (the CPU restatement of the mode does the same): scores = plain dot in index order * 1/sqrt(128), expf, softmax sum in double
 // in position order, PV in position order, times (float)(1 / sum)
 __global__ void __launch_bounds__(64) k_gg_attention(const float* __restrict__ qkv, int stride, int n_head, int n_kv, TokMeta tm, KvCache kv, int layer,
                                                      float* __restrict__ att, float* __restrict__ scores /* [ntok][n_head][n_ctx] */, int n_ctx) {

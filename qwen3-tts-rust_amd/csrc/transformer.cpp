@@ -389,7 +389,7 @@ void Transformer::alloc_workspace() {
     }
 }
 
-// ---- ggml-arithmetic mode (ggml_mode.hip): raw GGUF matrices, llama.cpp's portable arithmetic, bit-exact with oracle/q3o_ggml.c ----
+// ---- ggml-arithmetic mode (ggml_mode.hip): raw GGUF matrices, llama.cpp's portable arithmetic, bit-exact with the test suite's CPU restatement of the mode ----
 GgMat Transformer::gg_load(const Gguf& g, const std::string& name, int n_expect, int k_expect) {
     const GgufTensor& t = g.need(name);
     Q3_CHECK((int)t.ne[0] == k_expect && (int)t.ne[1] == n_expect, "ggml mode: shape of " + name);

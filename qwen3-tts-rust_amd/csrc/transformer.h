@@ -53,7 +53,7 @@ public:
     void set_fused_max_tokens(int n) { fused_max_tok_ = n; }
 
     // Q3_SPEC=ggml at construction: the opt-in "ggml-CPU" arithmetic mode (ggml_mode.hip) -- every forward() / head() then runs llama.cpp's portable
-    // arithmetic as oracle/q3o_ggml.c restates it, on raw copies of the GGUF matrices; slow by design, bit-exact with that oracle
+    // arithmetic (as the test suite's CPU restatement of the mode has it), on raw copies of the GGUF matrices; slow by design, bit-exact with that restatement
     bool ggml_mode() const { return ggml_mode_; }
 
     LaunchTimer* timer = nullptr;    // optional per-GEMV-launch event timing (instrumented bench leg): whole GEMV family
