@@ -24,6 +24,10 @@ static __device__ unsigned long long* g_q3_stamps = nullptr; // one per translat
 #define Q3_STAMP_FLUSH() do {} while (0)
 #endif
 
+// Workgroup barrier for LDS hand-offs that leaves the wave's GLOBAL loads and stores in flight.  __syncthreads() on gfx950 puts s_waitcnt vmcnt(0) in
+// front of s_barrier (the target has no automatic wait), i.e. every barrier also drains the weight stream and waits for the epilogue's stores to land.
+// Here only the LDS traffic is waited for, which is all an LDS producer -> consumer hand-off needs.
+__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __device__ __forceinline__ float h2f(uint32_t h) { return (float)__builtin_bit_cast(_Float16, (uint16_t)h); }
 // f32 -> f16, round-to-nearest-even of the *f32 value*.  The empty asm makes the operand opaque: without it the backend folds
 // `f2h(fma(a, b, c))` into v_fma_mixlo_f16, which rounds the exact a*b+c once to f16 and differs from the spec's

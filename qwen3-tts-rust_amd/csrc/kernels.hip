@@ -72,13 +72,17 @@ __global__ void __launch_bounds__(512) k_gemv_q8(Q8Mat w, int row0, int nrows, c
             for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
         }
     }
-    __syncthreads();
+    wg_barrier_lds();
     for (int t = threadIdx.x; t < R * MT; t += blockDim.x) { // blockDim may be smaller than R*MT (few segments, many tokens)
         const int m = t / R, rr = t % R;
         int nsg = nseg - sseg * 8;
         if (nsg > 8) nsg = 8;
-        float S = red[0][t];
-        for (int s = 1; s < nsg; s++) S = S + red[s][t];
+        float v[8]; // all eight reads first, then the in-order adds (a rolled loop pays one LDS round trip per add); rows s >= nsg are read and ignored
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = red[s][t];
+        float S = v[0];
+#pragma unroll
+        for (int s = 1; s < 8; s++) S = (s < nsg) ? S + v[s] : S;
         const int orow = blockIdx.x * R + rr, tok = tok0 + m;
         if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
     }
@@ -169,13 +173,17 @@ __global__ void __launch_bounds__(512) k_gemv_kq(Q8Mat w, int row0, int nrows, c
             for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
         }
     }
-    __syncthreads();
+    wg_barrier_lds();
     for (int t = threadIdx.x; t < R * MT; t += blockDim.x) {
         const int m = t / R, rr = t % R;
         int nsg = nseg - sseg * 8;
         if (nsg > 8) nsg = 8;
-        float S = red[0][t];
-        for (int s = 1; s < nsg; s++) S = S + red[s][t];
+        float v[8]; // all eight reads first, then the in-order adds (a rolled loop pays one LDS round trip per add); rows s >= nsg are read and ignored
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = red[s][t];
+        float S = v[0];
+#pragma unroll
+        for (int s = 1; s < 8; s++) S = (s < nsg) ? S + v[s] : S;
         const int orow = blockIdx.x * R + rr, tok = tok0 + m;
         if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
     }
@@ -363,10 +371,6 @@ __global__ void __launch_bounds__(512) k_gemm_q8_tok(Q8Mat w, int row0, int nrow
 // 16 accumulator values each lane owns.  B operand = a weight tile exactly as stored (lane = half*32 + row), A operand
 // = 16 activation bytes of token (lane & 31), half (lane >> 5).  Wave = segment, workgroup = super-segment.
 // =====================================================================================================
-// Workgroup barrier for LDS hand-offs that leaves the wave's GLOBAL loads and stores in flight.  __syncthreads() on gfx950 puts s_waitcnt vmcnt(0) in
-// front of s_barrier (the target has no automatic wait), i.e. every barrier also drains the weight stream and waits for the epilogue's stores to land.
-// Here only the LDS traffic is waited for, which is all an LDS producer -> consumer hand-off needs.
-__device__ __forceinline__ void wg_barrier_lds() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 #ifndef Q3_GEMM_AB
 #define Q3_GEMM_AB 4
 #endif

@@ -104,19 +104,21 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
         if (write_global && a.h_out) *reinterpret_cast<float4*>(a.h_out + (size_t)tok * d + 256 * c + 4 * lane) = v;
     }
     *reinterpret_cast<float4*>(vbuf + 256 * c + 4 * lane) = v;
-    __syncthreads();
+    wg_barrier_lds();
     if (wave == 0) {
-        const int nch = d >> 8;
+        const int nch = d >> 8; // <= 8 (d <= 2048): all chunk reads first, then the chain in chunk order (a rolled loop pays an LDS round trip per chunk)
+        float4 u[8];
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++) u[cc] = *reinterpret_cast<const float4*>(vbuf + 256 * (cc < nch ? cc : 0) + 4 * lane);
         float p = 0.0f;
-        for (int cc = 0; cc < nch; cc++) {
-            const float4 u = *reinterpret_cast<const float4*>(vbuf + 256 * cc + 4 * lane);
-            p = q3_fmaf(u.x, u.x, p); p = q3_fmaf(u.y, u.y, p); p = q3_fmaf(u.z, u.z, p); p = q3_fmaf(u.w, u.w, p);
-        }
+#pragma unroll
+        for (int cc = 0; cc < 8; cc++)
+            if (cc < nch) { p = q3_fmaf(u[cc].x, u[cc].x, p); p = q3_fmaf(u[cc].y, u[cc].y, p); p = q3_fmaf(u[cc].z, u[cc].z, p); p = q3_fmaf(u[cc].w, u[cc].w, p); }
         const float ss = wave_sum_bfly(p);
         const float mean = ss / (float)d;
         if (lane == 0) scal[0] = 1.0f / q3_sqrtf(mean + a.eps);
     }
-    __syncthreads();
+    wg_barrier_lds();
     const float scale = scal[0];
     float4 y;
     y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
@@ -140,7 +142,7 @@ __global__ void __launch_bounds__(512) k_rmsnorm_quant_wg(NormPro a, int d, int8
     __shared__ float scal_s[1];
     const int tok = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     norm_quant_wg(a, d, tok, true, lane, wave, xq_s, xd_s, vbuf_s, scal_s, true);
-    __syncthreads();
+    wg_barrier_lds();
     for (int i = threadIdx.x; i < d / 16; i += blockDim.x)
         *reinterpret_cast<uint4*>(xq + (size_t)tok * d + 16 * i) = *reinterpret_cast<const uint4*>(xq_s + 16 * i);
     for (int i = threadIdx.x; i < d / 32; i += blockDim.x) xd[(size_t)tok * (d / 32) + i] = xd_s[i];
@@ -177,7 +179,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
             const int tok = tok0 + m;
             norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
         }
-        __syncthreads();
+        wg_barrier_lds();
         ws.finish(half);
         float acc[MT];
 #pragma unroll
@@ -191,11 +193,15 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
             for (int m = 0; m < MT; m++) red[wave][m * R + r] = acc[m];
         }
     });
-    __syncthreads();
+    wg_barrier_lds();
     for (int t = threadIdx.x; t < R * MT; t += blockDim.x) { // whole R-lane groups stay together (blockDim % 64 == 0)
         const int m = t / R, rr = t % R;
-        float S = red[0][t];
-        for (int s = 1; s < nseg; s++) S = S + red[s][t];
+        float v[8]; // all eight reads first, then the in-order adds (a rolled loop pays one LDS round trip per add); rows s >= nseg are read and ignored
+#pragma unroll
+        for (int s = 0; s < 8; s++) v[s] = red[s][t];
+        float S = v[0];
+#pragma unroll
+        for (int s = 1; s < 8; s++) S = (s < nseg) ? S + v[s] : S;
         const int orow = blockIdx.x * R + rr, tok = tok0 + m;
         const bool ok = orow < nrows && tok < ntok;
         if (EPI == 0) {
@@ -280,7 +286,7 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
             const int tok = tok0 + m;
             norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
         }
-        __syncthreads();
+        wg_barrier_lds();
         wsg.finish(half); wsu.finish(half);
 #pragma unroll
         for (int m = 0; m < MT; m++) {
@@ -304,11 +310,15 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
             if (half == 0) { red[wave][0][m * 32 + r] = ag; red[wave][1][m * 32 + r] = au; }
         }
     });
-    __syncthreads();
+    wg_barrier_lds();
     for (int t = threadIdx.x; t < 32 * MT; t += blockDim.x) {
         const int m = t >> 5, rr = t & 31, tok = tok0 + m;
-        float G = red[0][0][t], U = red[0][1][t];
-        for (int s = 1; s < nseg; s++) { G = G + red[s][0][t]; U = U + red[s][1][t]; }
+        float vg[8], vu[8]; // (all reads first: see k_gemv_q8_norm)
+#pragma unroll
+        for (int s = 0; s < 8; s++) { vg[s] = red[s][0][t]; vu[s] = red[s][1][t]; }
+        float G = vg[0], U = vu[0];
+#pragma unroll
+        for (int s = 1; s < 8; s++) { G = (s < nseg) ? G + vg[s] : G; U = (s < nseg) ? U + vu[s] : U; }
         const float y = q3_swiglu(G, U);
         float amax = q3_fabsf(y);
         amax = fmaxf(amax, xor_lane<16>(amax)); amax = fmaxf(amax, xor_lane<8>(amax)); amax = fmaxf(amax, xor_lane<4>(amax));
@@ -419,7 +429,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
             }
         }
     }
-    __syncthreads();
+    wg_barrier_lds();
     const float scale = 0.08838834764831845f;
     float M = 0.0f, L = 0.0f, O[8];
 #pragma unroll
@@ -464,11 +474,11 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
         }
         const float wm = wave_max_bfly(s);
         if (lane == 0) wmax_s[wave] = wm;
-        __syncthreads();
+        wg_barrier_lds();
         const float mc = fmaxf(fmaxf(wmax_s[0], wmax_s[1]), fmaxf(wmax_s[2], wmax_s[3]));
         const float p = valid ? q3_expf(s - mc) : 0.0f;
         p_s[wave * 64 + lane] = p;
-        __syncthreads();
+        wg_barrier_lds();
         float S[8];
 #pragma unroll
         for (int i = 0; i < 8; i++) S[i] = 0.0f;
@@ -493,7 +503,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
             const float T = a2 + xor_lane<32>(a2);
             if (jj == 0) red_s[wave][dc * 8 + i] = T;
         }
-        __syncthreads();
+        wg_barrier_lds();
         if (wave == 0) {
             float a2 = p_s[lane];
             a2 = a2 + p_s[lane + 64]; a2 = a2 + p_s[lane + 128]; a2 = a2 + p_s[lane + 192];
@@ -515,7 +525,7 @@ __global__ void __launch_bounds__(256) k_attention_fused(const float* __restrict
                 M = mn;
             }
         }
-        __syncthreads();
+        wg_barrier_lds();
     }
     if (wave == 0) {
         float y[8];
@@ -624,7 +634,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
             Vw[slot * 128 + lane] = v1; Vw[slot * 128 + lane + 64] = v2;
         }
     }
-    __syncthreads();
+    wg_barrier_lds();
     Q3_STAMP(1);
     const bool valid = lane < n, cur = lane == slot;
     float a[HPW];
@@ -651,7 +661,7 @@ __global__ void __launch_bounds__(64) k_attention_short(const float* __restrict_
         p_s[hh][lane] = pv;
         L[hh] = wave_sum_bfly(pv);
     }
-    __syncthreads();
+    wg_barrier_lds();
     Q3_STAMP(3);
     const int dq = n_head * 128;
 #pragma unroll
