@@ -141,11 +141,16 @@ __global__ void __launch_bounds__(512) k_rmsnorm_quant_wg(NormPro a, int d, int8
     __shared__ __attribute__((aligned(16))) float vbuf_s[2048];
     __shared__ float scal_s[1];
     const int tok = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    Q3_STAMP_DECL;
+    Q3_STAMP(0);
     norm_quant_wg(a, d, tok, true, lane, wave, xq_s, xd_s, vbuf_s, scal_s, true);
+    Q3_STAMP(1);
     wg_barrier_lds();
     for (int i = threadIdx.x; i < d / 16; i += blockDim.x)
         *reinterpret_cast<uint4*>(xq + (size_t)tok * d + 16 * i) = *reinterpret_cast<const uint4*>(xq_s + 16 * i);
     for (int i = threadIdx.x; i < d / 32; i += blockDim.x) xd[(size_t)tok * (d / 32) + i] = xd_s[i];
+    Q3_STAMP(6);
+    Q3_STAMP_FLUSH();
 }
 void launch_rmsnorm_quant_wg(hipStream_t st, const NormPro& a, int d, int8_t* xq, uint16_t* xd, int ntok) {
     hipLaunchKernelGGL(k_rmsnorm_quant_wg, dim3(ntok), dim3(64 * (d / 256)), 0, st, a, d, xq, xd);

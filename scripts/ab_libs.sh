@@ -7,7 +7,7 @@ cp qwen3-tts-rust_amd/libq3tts.so $OUT/lib_backup.so
 for rep in 1 2; do
   for v in "$@"; do
     cp scripts/bin/ab/libq3tts_$v.so qwen3-tts-rust_amd/libq3tts.so
-    timeout -k 10 300 python bench.py --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/bench_${v}_$rep.json 2> $OUT/bench_${v}_$rep.err || { echo "$v failed"; tail -3 $OUT/bench_${v}_$rep.err; }
+    env ${AB_ENV:-Q3_NOP=1} timeout -k 10 300 python bench.py --no-cpu-baseline ${BENCH_ARGS:-} > $OUT/bench_${v}_$rep.json 2> $OUT/bench_${v}_$rep.err || { echo "$v failed"; tail -3 $OUT/bench_${v}_$rep.err; }
     python - <<PY
 import json
 o=json.load(open("$OUT/bench_${v}_$rep.json"))

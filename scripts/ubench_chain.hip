@@ -133,6 +133,29 @@ static void small_kernels_test(int ntok) {
     NormPro a{}; a.h_in = h.p; a.h_stride = d; a.parts = parts.p; a.nparts = 2; a.parts_stride = d; a.parts_slab = (size_t)ntok * d; a.h_out = hout.p; a.g = g.p; a.eps = 1e-6f;
     auto nrm = [&](int) { launch_rmsnorm_quant_wg(g_st, a, d, xq.p, xd.p, ntok); };
     printf("k_rmsnorm_quant_wg %d tokens d=%d 2 slabs: in-graph %.2f us/launch\n", ntok, d, time_graph(nrm, 40));
+    // the same norm behind the GEMM that produces its slabs (the predictor's down-projection, K = 3072 -> 2 slabs), as in the frame graph: its inputs are then
+    // lines other XCDs have just written
+    {
+        const int n = 1024, k = 3072;
+        std::vector<uint8_t> raw((size_t)n * (k / 32) * 34);
+        for (size_t i = 0; i < raw.size(); i++) raw[i] = (uint8_t)(i * 2654435761u >> 13);
+        for (size_t b = 0; b < (size_t)n * (k / 32); b++) { raw[b * 34] = 0x00; raw[b * 34 + 1] = 0x1C; }
+        DevBuf<uint8_t> storage; Q8Mat m = q8mat_from_host(raw.data(), n, k, storage);
+        DevBuf<int8_t> fq((size_t)ntok * k); DevBuf<uint16_t> fd((size_t)ntok * k / 32);
+        Q3_HIP(hipMemset(fq.p, 1, fq.n)); Q3_HIP(hipMemset(fd.p, 0x20, fd.n * 2));
+        auto gemm_only = [&](int) { launch_gemv_q8(g_st, m, 0, n, fq.p, fd.p, parts.p, d, ntok); };
+        auto pair = [&](int) { launch_gemv_q8(g_st, m, 0, n, fq.p, fd.p, parts.p, d, ntok); launch_rmsnorm_quant_wg(g_st, a, d, xq.p, xd.p, ntok); };
+        const float tg = time_graph(gemm_only, 40), tp = time_graph(pair, 40);
+        printf("down GEMM alone %.2f us; GEMM + norm pair %.2f us -> norm behind its producer costs %.2f us in-graph\n", tg, tp, tp - tg);
+        Q3_HIP(hipMemsetAsync(stamps.p, 0, stamps.n * 8, g_st));
+        set_stamp_buffer_fused(g_st, stamps.p);
+        for (int i = 0; i < 3; i++) pair(i);
+        Q3_HIP(hipStreamSynchronize(g_st));
+        std::vector<unsigned long long> hs(stamps.n); stamps.download(hs.data(), hs.size());
+        set_stamp_buffer_fused(g_st, nullptr);
+        const char* nn[7] = {"entry", "norm+quant done", "", "", "", "", "exit"};
+        print_stamps(hs, nn);
+    }
 }
 
 int main(int argc, char** argv) {
