@@ -4,6 +4,7 @@
 #include "onnx_exec.h"
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <functional>
 #include <limits>
 #include <set>
@@ -296,6 +297,113 @@ __global__ void __launch_bounds__(256) k_matmul(float* __restrict__ out, const f
         if (g.bias) v += g.beta * g.bias[m * g.bias_m + n * g.bias_n];
         out[(bz * g.M + m) * g.N + n] = v;
     }
+}
+// The same product on the matrix cores (exact-f32 `v_mfma_f32_32x32x2_f32`, as the codec's k_conv_gemm): 64 x 64 output tile per workgroup (4 waves, 2 x 2),
+// K tiles of 16 staged k-major in LDS with the next tile's loads in flight.  Operands through strides like k_matmul, plus an implicit-im2col B operand
+// for 1-D convolutions: K index -> (channel, tap), N index -> output position, element = x[c][n*stride - pad + tap*dil] (0 outside the row), so
+// Conv = W[M][C*kw] x im2col with the NCW output falling out row-major and nothing materialised.  ConvTranspose runs as W^T x X into per-tap
+// columns followed by k_col2im1d.  Used for every MatMul / Gemm / ungrouped Conv1d / ConvTranspose1d with at least 16 rows and columns.
+typedef float xf32x16 __attribute__((ext_vector_type(16)));
+struct MmFast {
+    int M, N, K;
+    int64_t a_b, a_m, a_k, b_b, b_k, b_n;
+    int conv, kw, cs, cp, cd, W;     // conv != 0: B is x[bz][c][pos] with row length W
+    const float* bias; int64_t bias_m, bias_n; float alpha, beta;
+};
+__global__ void __launch_bounds__(256) k_mm_mfma(float* __restrict__ out, const float* __restrict__ A, const float* __restrict__ B, MmFast g) {
+    __shared__ float As[16][65], Bs[16][65]; // 65: the k-fastest staging pattern writes 16 different k of one m -- distinct banks
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, wm = wave >> 1, wn = wave & 1;
+    const int m0 = blockIdx.y * 64, n0 = blockIdx.x * 64;
+    const float* a = A + (int64_t)blockIdx.z * g.a_b;
+    const float* b = B + (int64_t)blockIdx.z * g.b_b;
+    // which index runs fastest over the threads of a fetch: the one whose stride is 1 (coalescing); wave-uniform choices
+    const bool a_mfast = g.a_m == 1 && g.a_k != 1;
+    const bool b_nfast = g.conv ? true : (g.b_n == 1 || g.b_k != 1);
+    xf32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; i++) acc[i] = 0.0f;
+    float ra[4], rb[4];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int mm = a_mfast ? (tid & 63) : (tid >> 4) + 16 * i, kk = a_mfast ? (tid >> 6) + 4 * i : (tid & 15);
+            const int m = m0 + mm, k = k0 + kk;
+            ra[i] = (m < g.M && k < g.K) ? a[(int64_t)m * g.a_m + (int64_t)k * g.a_k] : 0.0f;
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int nn = b_nfast ? (tid & 63) : (tid >> 4) + 16 * i, kk = b_nfast ? (tid >> 6) + 4 * i : (tid & 15);
+            const int n = n0 + nn, k = k0 + kk;
+            float v = 0.0f;
+            if (n < g.N && k < g.K) {
+                if (g.conv) {
+                    const int c = k / g.kw, tap = k - c * g.kw;
+                    const int64_t pos = (int64_t)n * g.cs - g.cp + (int64_t)tap * g.cd;
+                    if (pos >= 0 && pos < g.W) v = b[(int64_t)c * g.W + pos];
+                } else v = b[(int64_t)k * g.b_k + (int64_t)n * g.b_n];
+            }
+            rb[i] = v;
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int mm = a_mfast ? (tid & 63) : (tid >> 4) + 16 * i, kk = a_mfast ? (tid >> 6) + 4 * i : (tid & 15);
+            As[kk][mm] = ra[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 4; i++) {
+            const int nn = b_nfast ? (tid & 63) : (tid >> 4) + 16 * i, kk = b_nfast ? (tid >> 6) + 4 * i : (tid & 15);
+            Bs[kk][nn] = rb[i];
+        }
+    };
+    fetch(0);
+    for (int k0 = 0; k0 < g.K; k0 += 16) {
+        stash();
+        __syncthreads();
+        if (k0 + 16 < g.K) fetch(k0 + 16);
+#pragma unroll
+        for (int kk = 0; kk < 16; kk += 2) {
+            const float av = As[kk + (lane >> 5)][wm * 32 + (lane & 31)];
+            const float bv = Bs[kk + (lane >> 5)][wn * 32 + (lane & 31)];
+            acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc, 0, 0, 0);
+        }
+        __syncthreads();
+    }
+    const int col = n0 + wn * 32 + (lane & 31);
+    if (col < g.N) {
+#pragma unroll
+        for (int r = 0; r < 16; r++) {
+            const int row = m0 + wm * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+            if (row < g.M) {
+                float v = g.alpha * acc[r];
+                if (g.bias) v += g.beta * g.bias[(int64_t)row * g.bias_m + (int64_t)col * g.bias_n];
+                out[((int64_t)blockIdx.z * g.M + row) * g.N + col] = v;
+            }
+        }
+    }
+}
+// overlap-add of a transposed 1-D convolution's per-tap columns Y[b][m*kw + k][i] (gather form, taps in increasing order): out[b][m][t]
+__global__ void k_col2im1d(float* __restrict__ out, const float* __restrict__ Y, const float* __restrict__ bias, int64_t M, int64_t OW, int64_t W, int kw, int s, int p, int d, int64_t n) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n) return;
+    const int64_t t = i % OW, m = (i / OW) % M, b = i / (OW * M);
+    float acc = bias ? bias[m] : 0.f;
+    const float* y = Y + (b * M + m) * kw * W;
+    for (int k = 0; k < kw; k++) {
+        const int64_t tt = t + p - (int64_t)k * d;
+        if (tt < 0 || tt % s != 0) continue;
+        const int64_t ix = tt / s;
+        if (ix < W) acc += y[(int64_t)k * W + ix];
+    }
+    out[i] = acc;
+}
+static const bool g_onnx_naive = [] { const char* e = std::getenv("Q3_ONNX_NAIVE"); return e && e[0] == '1'; }(); // A/B: one-output-per-thread kernels everywhere
+static bool mm_fast_ok(int64_t M, int64_t N, int64_t K, int64_t batch) {
+    return !g_onnx_naive && M >= 16 && N >= 16 && K >= 1 && M < (1 << 30) && N < (1 << 30) && K < (1 << 30) && batch <= 65535 && (M + 63) / 64 <= 65535;
+}
+static void launch_mm_fast(float* out, const float* A, const float* B, const MmFast& g, int64_t batch) {
+    hipLaunchKernelGGL(k_mm_mfma, dim3((unsigned)((g.N + 63) / 64), (unsigned)((g.M + 63) / 64), (unsigned)batch), dim3(256), 0, 0, out, A, B, g);
 }
 // direct 2-D convolution (1-D = H of 1), one output element per thread: general strides / pads / dilations / groups
 struct ConvArgs { int64_t N, C, H, W, M, OH, OW, kh, kw, sh, sw, ph, pw, dh, dw, groups; };
@@ -1162,6 +1270,12 @@ void OnnxSession::run() {
                 }
                 XTensor o = I.dev_tensor(1, os);
                 if (o.numel()) {
+                    if (mm_fast_ok(g.M, g.N, g.K, batch)) {
+                        MmFast f{};
+                        f.M = (int)g.M; f.N = (int)g.N; f.K = (int)g.K; f.a_b = g.a_b; f.a_m = g.a_m; f.a_k = g.a_k; f.b_b = g.b_b; f.b_k = g.b_k; f.b_n = g.b_n;
+                        f.bias = g.bias; f.bias_m = g.bias_m; f.bias_n = g.bias_n; f.alpha = g.alpha; f.beta = g.beta;
+                        launch_mm_fast(I.f(o), I.f(A), I.f(B), f, batch);
+                    } else
                     hipLaunchKernelGGL(k_matmul, dim3((unsigned)((g.N + 15) / 16), (unsigned)((g.M + 15) / 16), (unsigned)batch), dim3(256), 0, 0, I.f(o), I.f(A), I.f(B), g);
                     I.count();
                 }
@@ -1229,7 +1343,24 @@ void OnnxSession::run() {
                 XTensor o = I.dev_tensor(1, os);
                 const int64_t n = o.numel();
                 if (n) {
-                    if (op == "Conv") hipLaunchKernelGGL(k_conv2d, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), I.f(w), has(2) ? I.f(b) : nullptr, g, n);
+                    const bool one_d = sp == 1 && g.groups == 1 && g.W < (1 << 30) && g.OW < (1 << 30) && g.sw < (1 << 20) && g.pw < (1 << 30) && g.dw < (1 << 20) && g.kw < (1 << 20);
+                    if (op == "Conv" && one_d && mm_fast_ok(g.M, g.OW, g.C * g.kw, g.N)) {
+                        // implicit GEMM: W[M][C * kw] x im2col(x)[C * kw][OW] per batch element; the NCW output is the product's row-major layout
+                        MmFast f{};
+                        f.M = (int)g.M; f.N = (int)g.OW; f.K = (int)(g.C * g.kw); f.a_b = 0; f.a_m = g.C * g.kw; f.a_k = 1; f.b_b = g.C * g.W;
+                        f.conv = 1; f.kw = (int)g.kw; f.cs = (int)g.sw; f.cp = (int)g.pw; f.cd = (int)g.dw; f.W = (int)g.W;
+                        f.bias = has(2) ? I.f(b) : nullptr; f.bias_m = 1; f.bias_n = 0; f.alpha = 1.f; f.beta = 1.f;
+                        launch_mm_fast(I.f(o), I.f(w), I.f(x), f, g.N);
+                    } else if (op == "ConvTranspose" && one_d && mm_fast_ok(g.M * g.kw, g.W, g.C, g.N)) {
+                        // Y[b][m * kw + k][i] = sum_c w[c][m][k] x[b][c][i] (the weight tensor read as its own transpose), then the taps are overlap-added
+                        XTensor y = I.dev_tensor(1, {g.N, g.M * g.kw, g.W});
+                        MmFast f{};
+                        f.M = (int)(g.M * g.kw); f.N = (int)g.W; f.K = (int)g.C; f.a_b = 0; f.a_m = 1; f.a_k = g.M * g.kw; f.b_b = g.C * g.W; f.b_k = g.W; f.b_n = 1;
+                        f.alpha = 1.f; f.beta = 0.f;
+                        launch_mm_fast(I.f(y), I.f(w), I.f(x), f, g.N);
+                        I.count();
+                        hipLaunchKernelGGL(k_col2im1d, grid1(n), dim3(256), 0, 0, I.f(o), I.f(y), has(2) ? I.f(b) : nullptr, g.M, g.OW, g.W, (int)g.kw, (int)g.sw, (int)g.pw, (int)g.dw, n);
+                    } else if (op == "Conv") hipLaunchKernelGGL(k_conv2d, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), I.f(w), has(2) ? I.f(b) : nullptr, g, n);
                     else hipLaunchKernelGGL(k_convtr2d, grid1(n), dim3(256), 0, 0, I.f(o), I.f(x), I.f(w), has(2) ? I.f(b) : nullptr, g, n);
                     I.count();
                 }

@@ -284,6 +284,53 @@ def test_convolutions_and_pad_vs_torch(gpu, tmp_path):
         np.testing.assert_allclose(r[k], v.numpy(), rtol=1e-4, atol=2e-5, err_msg=k)
 
 
+def test_matrix_core_matmul_and_conv1d_vs_torch(gpu, tmp_path):
+    """MatMul / Gemm / ungrouped Conv1d / ConvTranspose1d with >= 16 rows and columns run on k_mm_mfma (exact-f32 matrix cores, implicit
+    im2col; ConvTranspose = W^T x X + k_col2im1d).  Shapes here are decoder-like and deliberately ragged: several 64 x 64 tiles with partial edges, K not a
+    multiple of 16, batch > 1, every stride pattern the operand loader distinguishes (row-major, transposed, broadcast batch), strides / dilations / asymmetric
+    pads / output_padding.  Reference: torch in float64."""
+    import torch
+    import torch.nn.functional as Fn
+    rng = np.random.default_rng(61)
+    f = lambda *sh: rng.standard_normal(sh).astype(np.float32)
+    a, b, w, bb = f(3, 70, 45), f(3, 45, 130), f(45, 200), f(1, 45, 33)
+    ga, gb, gc, gat = f(100, 77), f(90, 77), f(90), f(77, 100)
+    x = f(2, 40, 333)
+    w7, b7 = f(72, 40, 7), f(72)          # k = 7, dilation 3, pads (9, 9): the decoder's residual-unit convolution
+    w5 = f(50, 40, 5)                     # stride 2, pads (3, 1), no bias
+    w1, b1 = f(96, 40, 1), f(96)          # pointwise
+    xt = f(2, 48, 57)
+    wt, bt = f(48, 40, 16), f(40)         # stride 8, pads (4, 4): the decoder's upsampling block
+    wt2 = f(48, 24, 5)                    # stride 3, dilation 2, pads (1, 0), output_padding 2
+    inits = [W.tensor(n, v) for n, v in (("w", w), ("gb", gb), ("gc", gc), ("w7", w7), ("b7", b7), ("w5", w5), ("w1", w1), ("b1", b1), ("wt", wt), ("bt", bt), ("wt2", wt2))]
+    nodes = [
+        W.node("Transpose", ["bb"], ["bbT"], attrs=[W.attr_ints("perm", [0, 2, 1])]), W.node("Transpose", ["a"], ["a2"], attrs=[W.attr_ints("perm", [0, 2, 1])]),
+        W.node("MatMul", ["a", "b"], ["m_batched"]), W.node("MatMul", ["a", "w"], ["m_weight"]), W.node("MatMul", ["bbT", "a2"], ["m_bcast"]),
+        W.node("Gemm", ["ga", "gb", "gc"], ["g_tb"], attrs=[W.attr_int("transB", 1), W.attr_float("alpha", 0.5), W.attr_float("beta", 2.0)]),
+        W.node("Gemm", ["gat", "gb"], ["g_tab"], attrs=[W.attr_int("transA", 1), W.attr_int("transB", 1)]),
+        W.node("Conv", ["x", "w7", "b7"], ["c7"], attrs=[W.attr_ints("dilations", [3]), W.attr_ints("pads", [9, 9])]),
+        W.node("Conv", ["x", "w5"], ["c5"], attrs=[W.attr_ints("strides", [2]), W.attr_ints("pads", [3, 1])]),
+        W.node("Conv", ["x", "w1", "b1"], ["c1"]),
+        W.node("ConvTranspose", ["xt", "wt", "bt"], ["t8"], attrs=[W.attr_ints("strides", [8]), W.attr_ints("pads", [4, 4])]),
+        W.node("ConvTranspose", ["xt", "wt2"], ["t3"], attrs=[W.attr_ints("strides", [3]), W.attr_ints("dilations", [2]), W.attr_ints("pads", [1, 0]), W.attr_ints("output_padding", [2])]),
+    ]
+    D = lambda v: torch.from_numpy(v).double()
+    full_t3 = Fn.conv_transpose1d(D(xt), D(wt2), None, stride=3, dilation=2)          # length (57 - 1) * 3 + 2 * 4 + 1 = 177; pads (1, 0) + output_padding 2 -> 178
+    t3 = torch.zeros(2, 24, 178, dtype=torch.float64)
+    t3[:, :, :176] = full_t3[:, :, 1:]
+    ref = {
+        "m_batched": D(a) @ D(b), "m_weight": D(a) @ D(w), "m_bcast": D(bb).transpose(1, 2) @ D(a).transpose(1, 2),
+        "g_tb": 0.5 * D(ga) @ D(gb).T + 2.0 * D(gc), "g_tab": D(gat).T @ D(gb).T,
+        "c7": Fn.conv1d(D(x), D(w7), D(b7), dilation=3, padding=9), "c5": Fn.conv1d(Fn.pad(D(x), (3, 1)), D(w5), None, stride=2), "c1": Fn.conv1d(D(x), D(w1), D(b1)),
+        "t8": Fn.conv_transpose1d(D(xt), D(wt), D(bt), stride=8, padding=4), "t3": t3,
+    }
+    outs = [(k, F32, list(v.shape)) for k, v in ref.items()]
+    r = run_graph(gpu, tmp_path, nodes, inits, {"a": a, "b": b, "bb": bb, "ga": ga, "gat": gat, "x": x, "xt": xt}, outs)
+    for k, v in ref.items():
+        assert r[k].shape == tuple(v.shape), (k, r[k].shape, v.shape)
+        np.testing.assert_allclose(r[k], v.numpy(), rtol=1e-4, atol=1e-4, err_msg=k)
+
+
 def test_speaker_encoder_shaped_graph(gpu, tmp_path):
     """`mels` [1, n, 128] -> `spk_emb` [1, 2048] (onnx.rs:140-163): a small TDNN / squeeze-excitation / attentive-statistics-pooling network with the
     reference's input and output names, against the same network written in torch"""
