@@ -63,6 +63,25 @@ def test_oracle_vs_transformers_fixture(oracle):
     om.close()
 
 
+def test_oracle_predictor_loop_vs_transformers_fixture(oracle):
+    """The code-predictor loop (/root/reference/src/tts/engine.rs:596-640: two prompt rows, then 15 greedy passes, pass i reading slice i of the stacked
+    output matrix and feeding its code back through codebook table i) against what `transformers`' own `generate()` emits for its public implementation of
+    that loop (tests/golden/make_predictor_fixture.py): every pass's logits within TF_TOL and the 15 codes equal (smallest argmax margin of the fixture 0.15)."""
+    g = np.load(os.path.join(ROOT, "tests", "golden", "predictor_tf_expected.npz"))
+    D, L, H, HKV, FF, V, G, _ = [int(v) for v in g["meta"]]
+    om = oracle.Model(os.path.join(ROOT, "tests", "golden", "predictor_tf_f16.gguf"), 64)
+    om.eval(g["x"][0], [0, 0, 0, 0], D, 0, V)
+    _, lg = om.eval(g["x"][1], [1, 1, 1, 0], D, 0, V)
+    codes = []
+    for i in range(G - 1):
+        assert np.abs(lg - g["logits"][i]).max() < TF_TOL * max(1.0, np.abs(g["logits"][i]).max()), i
+        codes.append(int(np.argmax(lg)))
+        if i < G - 2:
+            _, lg = om.eval(g["tables"][i][codes[-1]].astype(np.float32), [i + 2, i + 2, i + 2, 0], D, (i + 1) * V, (i + 2) * V)
+    om.close()
+    assert codes == g["codes"].tolist()
+
+
 def test_oracle_q8_path_vs_transformers_fixture(oracle):
     """same numbers, the model quantised to Q8_0: the oracle's int8 path (block quantisation of activations, integer dots, scale chain)
     stays within the 8-bit quantisation noise of the float32 transformers result (measured 3e-2; a wrong scale, block order or sign
