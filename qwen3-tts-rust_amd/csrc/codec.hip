@@ -270,16 +270,21 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 // (BN = 64 wastes a quarter of the matrix work at N = 96) and the activation tile is fetched once per 96 output columns instead of once per 64.
 // One K tile in flight and ~110 VGPRs / 36 KB of LDS keep 4 workgroups per CU -- the middle ground between k_conv_gemm_h<1> (8 per CU, the
 // L2 -> LDS traffic 2.3 x larger) and a 256 x 96 register-blocked tile (2 per CU, spills; removed).  Reads pre-split operands as copies.
-template <int MR, int NT, int BK>
+// EPL = 1: the finished tile goes through LDS once so that every lane handles 4 consecutive columns of a row -- bias / residual / SnakeBeta parameter
+// loads and the output stores become 16-byte accesses (a row of the tile = one 384-byte burst) instead of 48 four-byte accesses per lane.
+template <int MR, int NT, int BK, int EPL>
 __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
     constexpr int BM = 128 * MR, BN = 32 * NT, LD = BK + 8; // LD: padded row stride (f16); 80 / 144 B keep the b128 fragment reads conflict-free
     constexpr int KQ = BK / 4, KC = BK / 8;                  // float4 pieces of an A row, uint4 pieces of a B row per K tile
     constexpr int NA = BM * KQ / 256;
     constexpr int NB = (BN * KC + 255) / 256;
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
+    constexpr int CLD = BN + 4;                              // row stride (floats) of the staged output tile
+    constexpr int STAGE_BYTES = 2 * (BM + BN) * LD * 2, TILE_BYTES = EPL ? BM * CLD * 4 : 0;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
+    _Float16 (*Ah)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem);
+    _Float16 (*Al)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + BM * LD * 2);
+    _Float16 (*Bh)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + 2 * BM * LD * 2);
+    _Float16 (*Bl)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + 2 * BM * LD * 2 + BN * LD * 2);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in launch order, so the column tiles of one row tile (and neighbouring row tiles, which
     // share the taps' halo rows) would land on 8 different private L2s and each fetch the activations from HBM again (measured: 532 MB per launch for a 63 MB
@@ -409,8 +414,51 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
             }
         }
     };
-    epilogue_rows(acc[0], m0 + wave * MR * 32);
-    if constexpr (MR > 1) epilogue_rows(acc[1], m0 + (wave * MR + 1) * 32);
+    if constexpr (EPL != 0 && MR == 1) {
+        // (the K loop ended on a barrier: the operand tiles are dead)
+        float (*Ct)[CLD] = reinterpret_cast<float (*)[CLD]>(smem);
+#pragma unroll
+        for (int u = 0; u < NT; u++)
+#pragma unroll
+            for (int r = 0; r < 16; r++) Ct[wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][u * 32 + (lane & 31)] = acc[0][u][r];
+        __syncthreads();
+        constexpr int C4 = BN / 4;
+        for (int e = tid; e < BM * C4; e += 256) {
+            const int rl = e / C4, col = n0 + (e % C4) * 4, row = m0 + rl;
+            if (row >= g.M) continue;
+            const float4 t = *reinterpret_cast<const float4*>(&Ct[rl][(e % C4) * 4]);
+            float v[4] = {t.x, t.y, t.z, t.w};
+            if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+            if (g.epi == EPI_GELU) {
+#pragma unroll
+                for (int c = 0; c < 4; c++) v[c] = 0.5f * v[c] * (1.0f + erff(v[c] * 0.70710678118654752f));
+            } else if (g.epi == EPI_RES_SCALE || g.epi == EPI_RES) {
+                const float4 rs = *reinterpret_cast<const float4*>(g.res + (size_t)row * g.ldr + (size_t)seg_of(row, g.r_segT) * g.r_skip + col);
+                if (g.epi == EPI_RES_SCALE) {
+                    const float4 sc = *reinterpret_cast<const float4*>(g.scale + col);
+                    v[0] = rs.x + sc.x * v[0]; v[1] = rs.y + sc.y * v[1]; v[2] = rs.z + sc.z * v[2]; v[3] = rs.w + sc.w * v[3];
+                } else { v[0] = rs.x + v[0]; v[1] = rs.y + v[1]; v[2] = rs.z + v[2]; v[3] = rs.w + v[3]; }
+            } else if (g.epi == EPI_SNAKE) {
+                const float4 ea = *reinterpret_cast<const float4*>(g.snake_ea + col), ib = *reinterpret_cast<const float4*>(g.snake_ib + col);
+                const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, ibv[4] = {ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+                for (int c = 0; c < 4; c++) { const float sn = snake_sin(v[c] * eav[c]); v[c] = v[c] + ibv[c] * (sn * sn); }
+            }
+            const size_t o = out_off(g, row, 0);
+            if (!g.o_split) *reinterpret_cast<float4*>(g.out + o + col) = make_float4(v[0], v[1], v[2], v[3]);
+            else {
+                _Float16* base = reinterpret_cast<_Float16*>(g.out + o);
+                h4v hi, lo;
+#pragma unroll
+                for (int c = 0; c < 4; c++) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+                *reinterpret_cast<h4v*>(base + col) = hi;
+                *reinterpret_cast<h4v*>(base + g.N + col) = lo;
+            }
+        }
+    } else {
+        epilogue_rows(acc[0], m0 + wave * MR * 32);
+        if constexpr (MR > 1) epilogue_rows(acc[1], m0 + (wave * MR + 1) * 32);
+    }
     static_assert(MR <= 2, "one epilogue call per row tile");
 }
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
@@ -493,7 +541,13 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
-        hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+        static const int epl_on = [] { const char* e = std::getenv("Q3_CODEC_H3_EPL"); return e ? atoi(e) : 1; }();
+        auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+        const bool vec_ok = epl_on && g.ldo % 4 == 0 && g.o_skip % 4 == 0 && a16(g.out) && (!g.bias || a16(g.bias)) &&
+                            (!(g.epi == EPI_RES || g.epi == EPI_RES_SCALE) || (g.ldr % 4 == 0 && g.r_skip % 4 == 0 && a16(g.res))) &&
+                            (g.epi != EPI_RES_SCALE || a16(g.scale)) && (g.epi != EPI_SNAKE || (a16(g.snake_ea) && a16(g.snake_ib)));
+        if (vec_ok) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 1>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+        else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 0>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
         return;
     }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
