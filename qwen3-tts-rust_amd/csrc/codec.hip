@@ -92,6 +92,45 @@ __device__ __forceinline__ float gemm_epilogue(const GemmArgs& g, float v, int r
     return v;
 }
 
+// the same epilogue for 4 consecutive columns of one row, with 16-byte parameter / residual loads and one 16-byte store (callers check alignment on the host)
+typedef _Float16 h4e_ __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void gemm_epilogue_store4(const GemmArgs& g, float4 t, int row, int col) {
+    float v[4] = {t.x, t.y, t.z, t.w};
+    if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
+    if (g.epi == EPI_GELU) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) v[c] = 0.5f * v[c] * (1.0f + erff(v[c] * 0.70710678118654752f));
+    } else if (g.epi == EPI_RES_SCALE || g.epi == EPI_RES) {
+        const float4 rs = *reinterpret_cast<const float4*>(g.res + (size_t)row * g.ldr + (size_t)seg_of(row, g.r_segT) * g.r_skip + col);
+        if (g.epi == EPI_RES_SCALE) {
+            const float4 sc = *reinterpret_cast<const float4*>(g.scale + col);
+            v[0] = rs.x + sc.x * v[0]; v[1] = rs.y + sc.y * v[1]; v[2] = rs.z + sc.z * v[2]; v[3] = rs.w + sc.w * v[3];
+        } else { v[0] = rs.x + v[0]; v[1] = rs.y + v[1]; v[2] = rs.z + v[2]; v[3] = rs.w + v[3]; }
+    } else if (g.epi == EPI_SNAKE) {
+        const float4 ea = *reinterpret_cast<const float4*>(g.snake_ea + col), ib = *reinterpret_cast<const float4*>(g.snake_ib + col);
+        const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, ibv[4] = {ib.x, ib.y, ib.z, ib.w};
+#pragma unroll
+        for (int c = 0; c < 4; c++) { const float sn = snake_sin(v[c] * eav[c]); v[c] = v[c] + ibv[c] * (sn * sn); }
+    }
+    const size_t o = out_off(g, row, 0);
+    if (!g.o_split) *reinterpret_cast<float4*>(g.out + o + col) = make_float4(v[0], v[1], v[2], v[3]);
+    else {
+        _Float16* base = reinterpret_cast<_Float16*>(g.out + o);
+        h4e_ hi, lo;
+#pragma unroll
+        for (int c = 0; c < 4; c++) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
+        *reinterpret_cast<h4e_*>(base + col) = hi;
+        *reinterpret_cast<h4e_*>(base + g.N + col) = lo;
+    }
+}
+// host side: every pointer and stride the 4-wide epilogue touches is 16-byte aligned / a multiple of 4 floats
+static bool epilogue4_ok(const GemmArgs& g) {
+    auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+    return g.N % 4 == 0 && g.ldo % 4 == 0 && g.o_skip % 4 == 0 && a16(g.out) && (!g.bias || a16(g.bias)) &&
+           (!(g.epi == EPI_RES || g.epi == EPI_RES_SCALE) || (g.ldr % 4 == 0 && g.r_skip % 4 == 0 && a16(g.res))) &&
+           (g.epi != EPI_RES_SCALE || a16(g.scale)) && (g.epi != EPI_SNAKE || (a16(g.snake_ea) && a16(g.snake_ib)));
+}
+
 // Workgroup = 4 waves; WM = waves along M.  Tile (32*WM) x (32*(4/WM)), BK = 16, LDS tiles stored k-major so the
 // MFMA fragment reads (lane -> 32 consecutive m or n) are conflict-free.  The next K tile is fetched into registers
 // while the current one is multiplied.  gridDim.z > 1 = split-K: each z writes a partial slab (no epilogue) that
@@ -172,14 +211,16 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
 // Same tiling, implicit-GEMM addressing, split-K and epilogues as k_conv_gemm<2>; BK = 32 (divides every cin of the decoder).
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
-template <int MR> // MR = 32-row tiles per wave along M: workgroup tile (64*MR) x 64; MR = 2 halves the weight re-reads and the LDS traffic per MFMA
+// EPL = 1: finished tile (or split-K partial) through LDS, 16-byte epilogue accesses (see k_conv_gemm_h3)
+template <int MR, int EPL> // MR = 32-row tiles per wave along M: workgroup tile (64*MR) x 64; MR = 2 halves the weight re-reads and the LDS traffic per MFMA
 __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
     constexpr int BM = 64 * MR, BN = 64, BK = 32, LD = 40; // LD: padded row stride (f16) of the LDS tiles
     constexpr int NA = BM * 8 / 256;                        // float4 fetches of A per thread per K tile
-    __shared__ __attribute__((aligned(16))) _Float16 Ah[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Al[BM][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bh[BN][LD];
-    __shared__ __attribute__((aligned(16))) _Float16 Bl[BN][LD];
+    constexpr int CLD = BN + 4;
+    struct Stage { _Float16 Ah[BM][LD], Al[BM][LD], Bh[BN][LD], Bl[BN][LD]; };
+    union Shared { Stage s; float Ct[EPL ? BM : 1][CLD]; };   // the finished tile reuses the operand tiles' space
+    __shared__ __attribute__((aligned(16))) Shared sh;
+    auto& Ah = sh.s.Ah; auto& Al = sh.s.Al; auto& Bh = sh.s.Bh; auto& Bl = sh.s.Bl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const int wm = wave >> 1, wn = wave & 1;
     const int m0 = blockIdx.y * BM, n0 = blockIdx.x * BN;
@@ -251,18 +292,34 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
         }
         __syncthreads();
     }
-    const int col = n0 + wn * 32 + (lane & 31);
-    if (col < g.N) {
+    if constexpr (EPL != 0) {
+        auto& Ct = sh.Ct; // (the K loop ended on a barrier: the operand tiles are dead)
 #pragma unroll
         for (int t = 0; t < MR; t++)
 #pragma unroll
-            for (int r = 0; r < 16; r++) {
-                const int row = m0 + (wm * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
-                if (row < g.M) {
-                    if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][r];
-                    else gemm_store(g, row, col, gemm_epilogue(g, acc[t][r], row, col));
+            for (int r = 0; r < 16; r++) Ct[(wm * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5)][wn * 32 + (lane & 31)] = acc[t][r];
+        __syncthreads();
+        for (int e = tid; e < BM * (BN / 4); e += 256) {
+            const int rl = e / (BN / 4), cl = (e % (BN / 4)) * 4, row = m0 + rl, col = n0 + cl;
+            if (row >= g.M || col >= g.N) continue; // N % 4 == 0 (host check): a 4-group is inside or outside as a whole
+            const float4 t4 = *reinterpret_cast<const float4*>(&Ct[rl][cl]);
+            if (ksplit > 1) *reinterpret_cast<float4*>(g.ws + ((size_t)blockIdx.z * g.M + row) * g.N + col) = t4;
+            else gemm_epilogue_store4(g, t4, row, col);
+        }
+    } else {
+        const int col = n0 + wn * 32 + (lane & 31);
+        if (col < g.N) {
+#pragma unroll
+            for (int t = 0; t < MR; t++)
+#pragma unroll
+                for (int r = 0; r < 16; r++) {
+                    const int row = m0 + (wm * MR + t) * 32 + (r & 3) + 8 * (r >> 2) + 4 * (lane >> 5);
+                    if (row < g.M) {
+                        if (ksplit > 1) g.ws[((size_t)blockIdx.z * g.M + row) * g.N + col] = acc[t][r];
+                        else gemm_store(g, row, col, gemm_epilogue(g, acc[t][r], row, col));
+                    }
                 }
-            }
+        }
     }
 }
 // 128 x (32 NT) form: the 4 waves stack along M (32 rows each) and every wave owns NT column tiles, so a k-step of 16 reads 2 + 2 NT LDS
@@ -279,12 +336,10 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     constexpr int NA = BM * KQ / 256;
     constexpr int NB = (BN * KC + 255) / 256;
     constexpr int CLD = BN + 4;                              // row stride (floats) of the staged output tile
-    constexpr int STAGE_BYTES = 2 * (BM + BN) * LD * 2, TILE_BYTES = EPL ? BM * CLD * 4 : 0;
-    __shared__ __attribute__((aligned(16))) unsigned char smem[STAGE_BYTES > TILE_BYTES ? STAGE_BYTES : TILE_BYTES];
-    _Float16 (*Ah)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem);
-    _Float16 (*Al)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + BM * LD * 2);
-    _Float16 (*Bh)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + 2 * BM * LD * 2);
-    _Float16 (*Bl)[LD] = reinterpret_cast<_Float16 (*)[LD]>(smem + 2 * BM * LD * 2 + BN * LD * 2);
+    struct Stage { _Float16 Ah[BM][LD], Al[BM][LD], Bh[BN][LD], Bl[BN][LD]; };
+    union Shared { Stage s; float Ct[EPL ? BM : 1][CLD]; };   // the finished tile reuses the operand tiles' space
+    __shared__ __attribute__((aligned(16))) Shared sh;
+    auto& Ah = sh.s.Ah; auto& Al = sh.s.Al; auto& Bh = sh.s.Bh; auto& Bl = sh.s.Bl;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     // XCD-aware tile order: workgroups are dealt to the 8 XCDs round-robin in launch order, so the column tiles of one row tile (and neighbouring row tiles, which
     // share the taps' halo rows) would land on 8 different private L2s and each fetch the activations from HBM again (measured: 532 MB per launch for a 63 MB
@@ -416,7 +471,7 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
     };
     if constexpr (EPL != 0 && MR == 1) {
         // (the K loop ended on a barrier: the operand tiles are dead)
-        float (*Ct)[CLD] = reinterpret_cast<float (*)[CLD]>(smem);
+        auto& Ct = sh.Ct;
 #pragma unroll
         for (int u = 0; u < NT; u++)
 #pragma unroll
@@ -426,40 +481,25 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
         for (int e = tid; e < BM * C4; e += 256) {
             const int rl = e / C4, col = n0 + (e % C4) * 4, row = m0 + rl;
             if (row >= g.M) continue;
-            const float4 t = *reinterpret_cast<const float4*>(&Ct[rl][(e % C4) * 4]);
-            float v[4] = {t.x, t.y, t.z, t.w};
-            if (g.bias) { const float4 b = *reinterpret_cast<const float4*>(g.bias + col); v[0] += b.x; v[1] += b.y; v[2] += b.z; v[3] += b.w; }
-            if (g.epi == EPI_GELU) {
-#pragma unroll
-                for (int c = 0; c < 4; c++) v[c] = 0.5f * v[c] * (1.0f + erff(v[c] * 0.70710678118654752f));
-            } else if (g.epi == EPI_RES_SCALE || g.epi == EPI_RES) {
-                const float4 rs = *reinterpret_cast<const float4*>(g.res + (size_t)row * g.ldr + (size_t)seg_of(row, g.r_segT) * g.r_skip + col);
-                if (g.epi == EPI_RES_SCALE) {
-                    const float4 sc = *reinterpret_cast<const float4*>(g.scale + col);
-                    v[0] = rs.x + sc.x * v[0]; v[1] = rs.y + sc.y * v[1]; v[2] = rs.z + sc.z * v[2]; v[3] = rs.w + sc.w * v[3];
-                } else { v[0] = rs.x + v[0]; v[1] = rs.y + v[1]; v[2] = rs.z + v[2]; v[3] = rs.w + v[3]; }
-            } else if (g.epi == EPI_SNAKE) {
-                const float4 ea = *reinterpret_cast<const float4*>(g.snake_ea + col), ib = *reinterpret_cast<const float4*>(g.snake_ib + col);
-                const float eav[4] = {ea.x, ea.y, ea.z, ea.w}, ibv[4] = {ib.x, ib.y, ib.z, ib.w};
-#pragma unroll
-                for (int c = 0; c < 4; c++) { const float sn = snake_sin(v[c] * eav[c]); v[c] = v[c] + ibv[c] * (sn * sn); }
-            }
-            const size_t o = out_off(g, row, 0);
-            if (!g.o_split) *reinterpret_cast<float4*>(g.out + o + col) = make_float4(v[0], v[1], v[2], v[3]);
-            else {
-                _Float16* base = reinterpret_cast<_Float16*>(g.out + o);
-                h4v hi, lo;
-#pragma unroll
-                for (int c = 0; c < 4; c++) { hi[c] = (_Float16)v[c]; lo[c] = (_Float16)(v[c] - (float)hi[c]); }
-                *reinterpret_cast<h4v*>(base + col) = hi;
-                *reinterpret_cast<h4v*>(base + g.N + col) = lo;
-            }
+            gemm_epilogue_store4(g, *reinterpret_cast<const float4*>(&Ct[rl][(e % C4) * 4]), row, col);
         }
     } else {
         epilogue_rows(acc[0], m0 + wave * MR * 32);
         if constexpr (MR > 1) epilogue_rows(acc[1], m0 + (wave * MR + 1) * 32);
     }
     static_assert(MR <= 2, "one epilogue call per row tile");
+}
+// 4 columns per thread (slab rows are N floats, N % 4 == 0): 16-byte slab reads, 16-byte epilogue accesses
+__global__ void __launch_bounds__(256) k_splitk_reduce4(GemmArgs g, int ksplit) {
+    const size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 4, mn = (size_t)g.M * g.N;
+    if (i >= mn) return;
+    const int row = (int)(i / g.N), col = (int)(i % g.N);
+    float4 v = *reinterpret_cast<const float4*>(g.ws + i);
+    for (int s = 1; s < ksplit; s++) {
+        const float4 w = *reinterpret_cast<const float4*>(g.ws + (size_t)s * mn + i);
+        v.x += w.x; v.y += w.y; v.z += w.z; v.w += w.w;
+    }
+    gemm_epilogue_store4(g, v, row, col);
 }
 __global__ void __launch_bounds__(256) k_splitk_reduce(GemmArgs g, int ksplit) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
@@ -542,10 +582,7 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
         static const int epl_on = [] { const char* e = std::getenv("Q3_CODEC_H3_EPL"); return e ? atoi(e) : 1; }();
-        auto a16 = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
-        const bool vec_ok = epl_on && g.ldo % 4 == 0 && g.o_skip % 4 == 0 && a16(g.out) && (!g.bias || a16(g.bias)) &&
-                            (!(g.epi == EPI_RES || g.epi == EPI_RES_SCALE) || (g.ldr % 4 == 0 && g.r_skip % 4 == 0 && a16(g.res))) &&
-                            (g.epi != EPI_RES_SCALE || a16(g.scale)) && (g.epi != EPI_SNAKE || (a16(g.snake_ea) && a16(g.snake_ib)));
+        const bool vec_ok = epl_on && epilogue4_ok(g);
         if (vec_ok) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 1>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
         else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 0>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
         return;
@@ -558,11 +595,19 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         static const int wg_target = [] { const char* e = std::getenv("Q3_CODEC_WGS"); return e ? atoi(e) : 256; }(); // split-K until this many workgroups
         int ks = 1;
         while (t2 * ks < wg_target && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
-        if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
-        else hipLaunchKernelGGL((k_conv_gemm_h<1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
+        static const int epl4 = [] { const char* e = std::getenv("Q3_CODEC_EPL4"); return e ? atoi(e) : 1; }();
+        const bool vec_ok = epl4 && epilogue4_ok(g) && (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0;
+        if (vec_ok) {
+            if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2, 1>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
+            else hipLaunchKernelGGL((k_conv_gemm_h<1, 1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
+        } else {
+            if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2, 0>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
+            else hipLaunchKernelGGL((k_conv_gemm_h<1, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
+        }
         if (ks > 1) {
             const size_t n = (size_t)g.M * g.N;
-            hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
+            if (vec_ok) hipLaunchKernelGGL(k_splitk_reduce4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, g, ks);
+            else hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, st, g, ks);
         }
         return;
     }
