@@ -481,7 +481,9 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
         for (int e = tid; e < BM * C4; e += 256) {
             const int rl = e / C4, col = n0 + (e % C4) * 4, row = m0 + rl;
             if (row >= g.M) continue;
-            gemm_epilogue_store4(g, *reinterpret_cast<const float4*>(&Ct[rl][(e % C4) * 4]), row, col);
+            const float4 t4 = *reinterpret_cast<const float4*>(&Ct[rl][(e % C4) * 4]);
+            if (ksplit > 1) *reinterpret_cast<float4*>(g.ws + ((size_t)blockIdx.z * g.M + row) * g.N + col) = t4;
+            else gemm_epilogue_store4(g, t4, row, col);
         }
     } else {
         epilogue_rows(acc[0], m0 + wave * MR * 32);
@@ -580,12 +582,34 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     g.xcd_swizzle = xcd_on;
     static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
-    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n && (g.N / 96) * ((g.M + 127) / 128) >= h3_min_wgs) {
-        static const int epl_on = [] { const char* e = std::getenv("Q3_CODEC_H3_EPL"); return e ? atoi(e) : 1; }();
-        const bool vec_ok = epl_on && epilogue4_ok(g);
-        if (vec_ok) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 1>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
-        else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 0>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
-        return;
+    static const int epl_on = [] { const char* e = std::getenv("Q3_CODEC_H3_EPL"); return e ? atoi(e) : 1; }();
+    // split-K for the 128 x 96 tile: deep-K GEMMs with few tiles (N = 768: K = 5376 = 168 K tiles on 128-256 workgroups, one wave per SIMD) are latency-bound;
+    // K is cut until Q3_CODEC_H3_WGS workgroups exist, partial slabs summed by k_splitk_reduce4.  Default 0 = never: alone the codec gains 5-8 % at 512-768
+    // (3.68 -> 3.40 ms per 16-stream pass), but next to the frame loop the extra workgroups cost more than they save (C3 664 -> 650-657 audio-s/s)
+    static const int h3_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_WGS"); return e ? atoi(e) : 0; }();
+    static const int h3_min_tiles = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_TILES"); return e ? atoi(e) : 96; }();
+    if (!small && wh && !g_codec_f32 && g.cin % 32 == 0 && h3_min_wgs > 0 && g.N % 96 == 0 && g.N <= h3_max_n) {
+        const int tiles3 = (g.N / 96) * ((g.M + 127) / 128);
+        const bool vec_ok = epl_on && epilogue4_ok(g) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
+        int ks = 1;
+        if (vec_ok && h3_wgs > 0 && tiles3 >= h3_min_tiles && tiles3 < h3_wgs) {
+            static const int cand[] = {2, 3, 4, 6, 7, 8, 12, 14, 16};
+            for (int c : cand) {
+                if (g.K % c != 0 || (g.K / c) % 32 != 0 || g.K / c < 256 || (size_t)c * g.M * g.N > ws_floats) continue;
+                ks = c;
+                if (tiles3 * c >= h3_wgs) break;
+            }
+        }
+        if (tiles3 * ks >= h3_min_wgs) {
+            g.ws = ws;
+            if (vec_ok) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 1>), dim3(g.N / 96, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
+            else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 0>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+            if (ks > 1) {
+                const size_t n = (size_t)g.M * g.N;
+                hipLaunchKernelGGL(k_splitk_reduce4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, g, ks);
+            }
+            return;
+        }
     }
     if (!small && wh && !g_codec_f32 && g.cin % 32 == 0) { // large M: split-f16 matrix cores (K tile 32)
         static const int big_m = [] { const char* e = std::getenv("Q3_CODEC_BM128"); return e ? atoi(e) : 1024; }(); // rows from which the 128-row tile is used
