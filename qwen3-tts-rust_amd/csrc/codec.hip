@@ -820,7 +820,12 @@ __global__ void __launch_bounds__(256) k_conv_out_wave(const float* __restrict__
     if (t >= n) return;
     const float* row = in_ext + map_row(im, t) * C; // 7 consecutive rows of C floats = one contiguous span of 7*C
     float a = 0.0f;
-    for (int i = lane; i < 7 * C; i += 64) a += w[i] * row[i];
+    if ((C & 3) == 0) { // 16-byte loads (rows start on C-float boundaries; C % 4 == 0 for every decoder width)
+        for (int i = lane; i < 7 * C / 4; i += 64) {
+            const float4 x = *reinterpret_cast<const float4*>(row + 4 * i), ww = *reinterpret_cast<const float4*>(w + 4 * i);
+            a += ww.x * x.x + ww.y * x.y + ww.z * x.z + ww.w * x.w;
+        }
+    } else for (int i = lane; i < 7 * C; i += 64) a += w[i] * row[i];
     for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
     a += bias;
     if (lane == 0) pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
