@@ -580,7 +580,7 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
     g.ws = ws;
     static const int xcd_on = [] { const char* e = std::getenv("Q3_CODEC_XCD"); return e ? atoi(e) : 1; }();
     g.xcd_swizzle = xcd_on;
-    static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 256; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
+    static const int h3_min_wgs = [] { const char* e = std::getenv("Q3_CODEC_H3_MIN_WGS"); return e ? atoi(e) : 128; }(); // workgroups from which the 128 x 96 tile serves (0 = never)
     static const int h3_max_n = [] { const char* e = std::getenv("Q3_CODEC_H3_MAXN"); return e ? atoi(e) : 1 << 30; }();
     static const int epl_on = [] { const char* e = std::getenv("Q3_CODEC_H3_EPL"); return e ? atoi(e) : 1; }();
     // split-K for the 128 x 96 tile: deep-K GEMMs with few tiles (N = 768: K = 5376 = 168 K tiles on 128-256 workgroups, one wave per SIMD) are latency-bound;
