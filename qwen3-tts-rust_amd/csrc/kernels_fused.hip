@@ -772,24 +772,56 @@ __global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x
         out[(size_t)tok * out_stride + o] = sum;
     }
 }
-// Many tokens: thread = one (token, output) chain; the 16 outputs of a workgroup read the weight slab straight from global (the 16
-// token groups of the workgroup hit the same 64-byte line), activations of 16 tokens are staged in LDS as [i][token].
+// Many tokens: thread = one (token, output) chain (the reference's order: products added one by one in input order, no fma).  The chain is 2048
+// dependent adds; what made the first version slow (104 us at 64 tokens) was not the chain but 128 serialised batches of global weight loads behind it.
+// Now the workgroup's weight slab [n_in][16] and its 16 activation rows go through LDS in chunks of 512 inputs -- fetched with 16-byte loads one chunk
+// ahead (registers), stored transposed ([output][input], [token][input]; row stride 516 floats keeps the 16-byte reads of 16 rows on distinct banks) -- and
+// the chain reads 4 inputs per ds_read_b128.
 __global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x, int x_stride, const float* __restrict__ Wblk,
                                                     const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
                                                     int out_stride, int ntok) {
-    extern __shared__ __attribute__((aligned(16))) float xs[]; // [n_in][16]
+    constexpr int KC = 512, LDP = KC + 4;
+    __shared__ __attribute__((aligned(16))) float xs[16][LDP];
+    __shared__ __attribute__((aligned(16))) float ws[16][LDP];
     const int ob = blockIdx.x, t0 = blockIdx.y * 16, tid = threadIdx.x;
     const int o16 = tid & 15, tl = tid >> 4;
-    for (int e = tid; e < n_in * 16; e += 256) {
-        const int t = e / n_in, i = e % n_in; // coalesced global reads along i
-        xs[i * 16 + t] = (t0 + t < ntok) ? x[(size_t)(t0 + t) * x_stride + i] : 0.0f;
-    }
-    __syncthreads();
-    const float* wp = Wblk + (size_t)ob * n_in * 16 + o16;
+    const float* wslab = Wblk + (size_t)ob * n_in * 16;
+    float4 rx[8], rw[8];
+    auto fetch = [&](int k0) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;               // x: 16 tokens x 128 float4
+            const int t = e >> 7, i4 = e & 127;
+            rx[j] = (t0 + t < ntok) ? *reinterpret_cast<const float4*>(x + (size_t)(t0 + t) * x_stride + k0 + 4 * i4) : make_float4(0.f, 0.f, 0.f, 0.f);
+            rw[j] = *reinterpret_cast<const float4*>(wslab + (size_t)k0 * 16 + 4 * (size_t)e); // W: 512 inputs x 4 float4 (outputs 4q .. 4q + 3 of input e / 4)
+        }
+    };
+    auto stash = [&]() {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            const int e = tid + 256 * j;
+            *reinterpret_cast<float4*>(&xs[e >> 7][4 * (e & 127)]) = rx[j];
+            const int i = e >> 2, q = (e & 3) * 4;
+            ws[q + 0][i] = rw[j].x; ws[q + 1][i] = rw[j].y; ws[q + 2][i] = rw[j].z; ws[q + 3][i] = rw[j].w;
+        }
+    };
     const int o = ob * 16 + o16;
     float sum = b[o];
-#pragma unroll 16
-    for (int i = 0; i < n_in; i++) { const float t = xs[i * 16 + tl] * wp[(size_t)i * 16]; sum = sum + t; }
+    fetch(0);
+    for (int k0 = 0; k0 < n_in; k0 += KC) {
+        stash();
+        __syncthreads();
+        if (k0 + KC < n_in) fetch(k0 + KC);
+#pragma unroll 8
+        for (int i = 0; i < KC; i += 4) {
+            const float4 xv = *reinterpret_cast<const float4*>(&xs[tl][i]), wv = *reinterpret_cast<const float4*>(&ws[o16][i]);
+            float t = xv.x * wv.x; sum = sum + t;
+            t = xv.y * wv.y; sum = sum + t;
+            t = xv.z * wv.z; sum = sum + t;
+            t = xv.w * wv.w; sum = sum + t;
+        }
+        __syncthreads();
+    }
     if (t0 + tl < ntok) out[(size_t)(t0 + tl) * out_stride + o] = sum;
 }
 static bool g_attr_set[64] = {}, g_attr_mt[64] = {}; // the dynamic-LDS opt-in is per device
@@ -798,7 +830,6 @@ void init_fused_kernel_attributes() {
     int dev = 0;
     Q3_HIP(hipGetDevice(&dev));
     if (dev < 0 || dev > 63) return;
-    if (!g_attr_mt[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); g_attr_mt[dev] = true; }
     if (!g_attr_set[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); g_attr_set[dev] = true; }
 }
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
@@ -809,9 +840,9 @@ void launch_project_blk(hipStream_t st, const float* x, int x_stride, const floa
     dev = dev < 0 || dev > 63 ? 0 : dev;
     static const int mt_min = [] { const char* e = std::getenv("Q3_PROJECT_MT_MIN"); return e ? atoi(e) : 3; }(); // experiment knob
     if (ntok >= mt_min) {
-        if (!attr_mt[dev]) { (void)hipFuncSetAttribute((const void*)k_project_mt, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_mt[dev] = true; }
-        hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), (size_t)n_in * 16 * sizeof(float), st, x, x_stride, Wblk, b,
-                           n_in, n_out, out, out_stride, ntok);
+        (void)attr_mt;
+        if (n_in % 512 != 0 || x_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) throw Error("k_project_mt: n_in must be a multiple of 512 and the rows 16-byte aligned");
+        hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), 0, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride, ntok);
         return;
     }
     const size_t lds = (size_t)n_in * 17 * sizeof(float);
