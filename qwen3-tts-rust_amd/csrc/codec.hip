@@ -212,7 +212,8 @@ __global__ void __launch_bounds__(256) k_conv_gemm(GemmArgs g) {
 typedef _Float16 h8v __attribute__((ext_vector_type(8)));
 typedef _Float16 h4v __attribute__((ext_vector_type(4)));
 // EPL = 1: finished tile (or split-K partial) through LDS, 16-byte epilogue accesses (see k_conv_gemm_h3)
-template <int MR, int EPL> // MR = 32-row tiles per wave along M: workgroup tile (64*MR) x 64; MR = 2 halves the weight re-reads and the LDS traffic per MFMA
+// SPLIT = pre-split operands (g.a_split); as in k_conv_gemm_h3 every K-loop load is unconditional (clamped rows) and the loop's barriers wait for LDS only
+template <int MR, int EPL, bool SPLIT> // MR = 32-row tiles per wave along M: workgroup tile (64*MR) x 64; MR = 2 halves the weight re-reads and the LDS traffic per MFMA
 __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
     constexpr int BM = 64 * MR, BN = 64, BK = 32, LD = 40; // LD: padded row stride (f16) of the LDS tiles
     constexpr int NA = BM * 8 / 256;                        // float4 fetches of A per thread per K tile
@@ -234,47 +235,40 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
     uint4 rh, rl;
     int arow[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / 8; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
-    const int wrow = n0 + tid / 4, wk = 8 * (tid & 3);
+    for (int i = 0; i < NA; i++) { int mm = m0 + (tid + i * 256) / 8; mm = mm < g.M ? mm : g.M - 1; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
+    const int wrow = (n0 + tid / 4 < g.N) ? n0 + tid / 4 : g.N - 1, wk = 8 * (tid & 3); // columns beyond N re-read row N - 1 (their outputs are never stored)
     auto fetch = [&](int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin; // BK divides cin, so a K tile never straddles taps
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) ra[i] = g.a_split ? load_a4_split_raw(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * kq)
-                                                : *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+            const int kq = (tid + i * 256) % 8;
+            const size_t row = (size_t)(arow[i] + j * g.dil);
+            if constexpr (SPLIT) ra[i] = load_a4_split_raw(g, row, ci0 + 4 * kq);
+            else ra[i] = *reinterpret_cast<const float4*>(g.A + row * g.lda + ci0 + 4 * kq);
         }
-        rh = make_uint4(0, 0, 0, 0); rl = make_uint4(0, 0, 0, 0);
-        if (wrow < g.N) {
-            rh = *reinterpret_cast<const uint4*>(Wh + (size_t)wrow * g.K + k0 + wk);
-            rl = *reinterpret_cast<const uint4*>(Wl + (size_t)wrow * g.K + k0 + wk);
-        }
+        rh = *reinterpret_cast<const uint4*>(Wh + (size_t)wrow * g.K + k0 + wk);
+        rl = *reinterpret_cast<const uint4*>(Wl + (size_t)wrow * g.K + k0 + wk);
     };
     auto stash = [&]() {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / 8, kq = e % 8;
-            if (g.a_split) { // operands arrive as hi / lo halfs: a copy
+            if constexpr (SPLIT) { // operands arrive as hi / lo halfs: a copy
                 *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(ra[i].x, ra[i].y);
                 *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(ra[i].z, ra[i].w);
-                continue;
-            }
-            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            h4v hi, lo;
+            } else {
+                const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
+                h4v hi, lo;
 #pragma unroll
-            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
-            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
-            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+                for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+                *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
+                *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+            }
         }
         *reinterpret_cast<uint4*>(&Bh[tid / 4][wk]) = rh;
         *reinterpret_cast<uint4*>(&Bl[tid / 4][wk]) = rl;
     };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
+    auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int ko = kk + 8 * (lane >> 5); // operand lane l: row l & 31, 8 consecutive k of half l >> 5 (A and B use the same split)
@@ -290,8 +284,21 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
                 acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, acc[t], 0, 0, 0);
             }
         }
-        __syncthreads();
+    };
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    fetch(kbeg);
+    int k0 = kbeg;
+    for (; k0 + BK < kend; k0 += BK) { // every refill unconditional (see k_conv_gemm_h3)
+        stash();
+        lds_barrier();
+        fetch(k0 + BK);
+        multiply();
+        lds_barrier();
     }
+    stash();
+    lds_barrier();
+    multiply();
+    __syncthreads(); // the epilogue reuses the operand tiles
     if constexpr (EPL != 0) {
         auto& Ct = sh.Ct; // (the K loop ended on a barrier: the operand tiles are dead)
 #pragma unroll
@@ -329,7 +336,10 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h(GemmArgs g, const _Float16*
 // L2 -> LDS traffic 2.3 x larger) and a 256 x 96 register-blocked tile (2 per CU, spills; removed).  Reads pre-split operands as copies.
 // EPL = 1: the finished tile goes through LDS once so that every lane handles 4 consecutive columns of a row -- bias / residual / SnakeBeta parameter
 // loads and the output stores become 16-byte accesses (a row of the tile = one 384-byte burst) instead of 48 four-byte accesses per lane.
-template <int MR, int NT, int BK, int EPL>
+// PF = K tiles whose loads are in flight in registers; SPLIT = operands arrive pre-split (g.a_split) -- a template parameter, and every load of the K loop is
+// unconditional (rows beyond M re-read row M - 1, spare loader slots re-read a valid weight row; their results are never stored): with exec-mask
+// branches around the loads the compiler's wait-count pass falls back to s_waitcnt vmcnt(0) at every join, which serialises any prefetch.
+template <int MR, int NT, int BK, int EPL, int PF, bool SPLIT>
 __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16* __restrict__ Wh, const _Float16* __restrict__ Wl) {
     constexpr int BM = 128 * MR, BN = 32 * NT, LD = BK + 8; // LD: padded row stride (f16); 80 / 144 B keep the b128 fragment reads conflict-free
     constexpr int KQ = BK / 4, KC = BK / 8;                  // float4 pieces of an A row, uint4 pieces of a B row per K tile
@@ -360,57 +370,51 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
         for (int u = 0; u < NT; u++)
 #pragma unroll
             for (int i = 0; i < 16; i++) acc[t][u][i] = 0.0f;
-    float4 ra[NA];
-    uint4 rh[NB], rl[NB];
     int arow[NA];
 #pragma unroll
-    for (int i = 0; i < NA; i++) { const int mm = m0 + (tid + i * 256) / KQ; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
-    auto fetch = [&](int k0) {
+    for (int i = 0; i < NA; i++) { int mm = m0 + (tid + i * 256) / KQ; mm = mm < g.M ? mm : g.M - 1; arow[i] = mm + seg_of(mm, g.a_segT) * g.a_skip; }
+    struct Regs { float4 ra[NA]; uint4 rh[NB], rl[NB]; };
+    auto fetch = [&](Regs& s, int k0) {
         const int j = k0 / g.cin, ci0 = k0 % g.cin;
 #pragma unroll
         for (int i = 0; i < NA; i++) {
-            const int e = tid + i * 256, r = e / KQ, kq = e % KQ;
-            ra[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-            if (m0 + r < g.M) ra[i] = g.a_split ? load_a4_split_raw(g, (size_t)(arow[i] + j * g.dil), ci0 + 4 * kq)
-                                                : *reinterpret_cast<const float4*>(g.A + (size_t)(arow[i] + j * g.dil) * g.lda + ci0 + 4 * kq);
+            const int kq = (tid + i * 256) % KQ;
+            const size_t row = (size_t)(arow[i] + j * g.dil);
+            if constexpr (SPLIT) s.ra[i] = load_a4_split_raw(g, row, ci0 + 4 * kq);
+            else s.ra[i] = *reinterpret_cast<const float4*>(g.A + row * g.lda + ci0 + 4 * kq);
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
-            const int e = tid + i * 256, r = e / KC, wk = 8 * (e % KC);
-            rh[i] = make_uint4(0, 0, 0, 0); rl[i] = make_uint4(0, 0, 0, 0);
-            if (e < BN * KC && n0 + r < g.N) {
-                rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
-                rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
-            }
+            int e = tid + i * 256;
+            e = e < BN * KC ? e : e - 256;              // spare slots of the last round re-read a valid piece (never written to LDS)
+            const int r = e / KC, wk = 8 * (e % KC);
+            s.rh[i] = *reinterpret_cast<const uint4*>(Wh + (size_t)(n0 + r) * g.K + k0 + wk);
+            s.rl[i] = *reinterpret_cast<const uint4*>(Wl + (size_t)(n0 + r) * g.K + k0 + wk);
         }
     };
-    auto stash = [&]() {
+    auto stash = [&](const Regs& s) {
 #pragma unroll
         for (int i = 0; i < NA; i++) {
             const int e = tid + i * 256, r = e / KQ, kq = e % KQ;
-            if (g.a_split) {
-                *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(ra[i].x, ra[i].y);
-                *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(ra[i].z, ra[i].w);
-                continue;
-            }
-            const float x[4] = {ra[i].x, ra[i].y, ra[i].z, ra[i].w};
-            h4v hi, lo;
+            if constexpr (SPLIT) {
+                *reinterpret_cast<float2*>(&Ah[r][4 * kq]) = make_float2(s.ra[i].x, s.ra[i].y);
+                *reinterpret_cast<float2*>(&Al[r][4 * kq]) = make_float2(s.ra[i].z, s.ra[i].w);
+            } else {
+                const float x[4] = {s.ra[i].x, s.ra[i].y, s.ra[i].z, s.ra[i].w};
+                h4v hi, lo;
 #pragma unroll
-            for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
-            *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
-            *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+                for (int c = 0; c < 4; c++) { hi[c] = (_Float16)x[c]; lo[c] = (_Float16)(x[c] - (float)hi[c]); }
+                *reinterpret_cast<h4v*>(&Ah[r][4 * kq]) = hi;
+                *reinterpret_cast<h4v*>(&Al[r][4 * kq]) = lo;
+            }
         }
 #pragma unroll
         for (int i = 0; i < NB; i++) {
             const int e = tid + i * 256, r = e / KC, wk = 8 * (e % KC);
-            if (e < BN * KC) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = rl[i]; }
+            if (e < BN * KC) { *reinterpret_cast<uint4*>(&Bh[r][wk]) = s.rh[i]; *reinterpret_cast<uint4*>(&Bl[r][wk]) = s.rl[i]; }
         }
     };
-    fetch(kbeg);
-    for (int k0 = kbeg; k0 < kend; k0 += BK) {
-        stash();
-        __syncthreads();
-        if (k0 + BK < kend) fetch(k0 + BK);
+    auto multiply = [&]() {
 #pragma unroll
         for (int kk = 0; kk < BK; kk += 16) {
             const int ko = kk + 8 * (lane >> 5);
@@ -448,8 +452,39 @@ __global__ void __launch_bounds__(256) k_conv_gemm_h3(GemmArgs g, const _Float16
                 }
             }
         }
-        __syncthreads();
+    };
+    // workgroup barriers of the K loop wait for LDS traffic only: __syncthreads() would also drain the prefetch (s_waitcnt vmcnt(0))
+    auto lds_barrier = [] { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    Regs st[PF];
+#pragma unroll
+    for (int j = 0; j < PF; j++)
+        if (kbeg + j * BK < kend) fetch(st[j], kbeg + j * BK);
+    int k0 = kbeg;
+    // steady state: every refill is unconditional, so the wait before a stash is a counted vmcnt that leaves the other stages' loads in flight
+    // (a conditional refill makes the wait-count pass assume the worst path and drain everything)
+    for (; k0 + 2 * PF * BK <= kend; k0 += PF * BK) {
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            stash(st[j]);
+            lds_barrier();
+            fetch(st[j], k0 + (j + PF) * BK);
+            multiply();
+            lds_barrier();
+        }
     }
+    for (; k0 < kend; k0 += PF * BK) { // the last tiles
+#pragma unroll
+        for (int j = 0; j < PF; j++) {
+            if (k0 + j * BK < kend) { // (uniform)
+                stash(st[j]);
+                lds_barrier();
+                if (k0 + (j + PF) * BK < kend) fetch(st[j], k0 + (j + PF) * BK);
+                multiply();
+                lds_barrier();
+            }
+        }
+    }
+    __syncthreads(); // the epilogue reuses the operand tiles
     // rows outermost: one row's addresses live at a time (columns outermost made the compiler keep every row's 64-bit addresses in
     // registers: 256 VGPRs, one wave per SIMD).  One call per row tile: a `for t` loop is "too large to unroll" and turns acc[t] into a
     // scratch array.
@@ -602,8 +637,11 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         }
         if (tiles3 * ks >= h3_min_wgs) {
             g.ws = ws;
-            if (vec_ok) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 1>), dim3(g.N / 96, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
-            else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, 0>), dim3(g.N / 96, (g.M + 127) / 128, 1), dim3(256), 0, st, g, wh, wl);
+            const dim3 grid3(g.N / 96, (g.M + 127) / 128, vec_ok ? ks : 1);
+#define Q3_H3(EPLV, PFV) do { if (g.a_split) hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, EPLV, PFV, true>), grid3, dim3(256), 0, st, g, wh, wl); \
+                              else hipLaunchKernelGGL((k_conv_gemm_h3<1, 3, 32, EPLV, PFV, false>), grid3, dim3(256), 0, st, g, wh, wl); } while (0)
+            if (!vec_ok) Q3_H3(0, 1); else Q3_H3(1, 1); // PF = 2 / 3 measured equal at 64 slots and slower at 256 (profiles/r02_codec_ab_sweeps.txt)
+#undef Q3_H3
             if (ks > 1) {
                 const size_t n = (size_t)g.M * g.N;
                 hipLaunchKernelGGL(k_splitk_reduce4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, g, ks);
@@ -621,13 +659,12 @@ static void gemm(hipStream_t st, GemmArgs g, float* ws, size_t ws_floats, const 
         while (t2 * ks < wg_target && ks < 16 && (g.K / (ks * 2)) % 32 == 0 && g.K / (ks * 2) >= 128 && (size_t)(ks * 2) * g.M * g.N <= ws_floats) ks *= 2;
         static const int epl4 = [] { const char* e = std::getenv("Q3_CODEC_EPL4"); return e ? atoi(e) : 1; }();
         const bool vec_ok = epl4 && epilogue4_ok(g) && (reinterpret_cast<uintptr_t>(g.ws) & 15) == 0;
-        if (vec_ok) {
-            if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2, 1>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
-            else hipLaunchKernelGGL((k_conv_gemm_h<1, 1>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
-        } else {
-            if (tall) hipLaunchKernelGGL((k_conv_gemm_h<2, 0>), dim3((g.N + 63) / 64, (g.M + 127) / 128, ks), dim3(256), 0, st, g, wh, wl);
-            else hipLaunchKernelGGL((k_conv_gemm_h<1, 0>), dim3((g.N + 63) / 64, (g.M + 63) / 64, ks), dim3(256), 0, st, g, wh, wl);
-        }
+#define Q3_H(MRV, EPLV, GRID) do { if (g.a_split) hipLaunchKernelGGL((k_conv_gemm_h<MRV, EPLV, true>), GRID, dim3(256), 0, st, g, wh, wl); \
+                                   else hipLaunchKernelGGL((k_conv_gemm_h<MRV, EPLV, false>), GRID, dim3(256), 0, st, g, wh, wl); } while (0)
+        const dim3 grid_t((g.N + 63) / 64, (g.M + 127) / 128, ks), grid_s((g.N + 63) / 64, (g.M + 63) / 64, ks);
+        if (vec_ok) { if (tall) Q3_H(2, 1, grid_t); else Q3_H(1, 1, grid_s); }
+        else { if (tall) Q3_H(2, 0, grid_t); else Q3_H(1, 0, grid_s); }
+#undef Q3_H
         if (ks > 1) {
             const size_t n = (size_t)g.M * g.N;
             if (vec_ok) hipLaunchKernelGGL(k_splitk_reduce4, dim3((unsigned)((n / 4 + 255) / 256)), dim3(256), 0, st, g, ks);
