@@ -164,6 +164,37 @@ def test_fullsize_codec_group16_vs_oracle(gpu, oracle, full_model):
     oc.close(); gd.close()
 
 
+def test_fullsize_codec_fallback_epilogues_match_the_16_byte_ones(gpu, full_model, tmp_path):
+    """The split-f16 GEMMs finish their tiles through LDS with 16-byte accesses (k_conv_gemm_h3<.., EPL = 1>, k_conv_gemm_h<.., 1>, k_splitk_reduce4) whenever
+    strides and pointers allow -- always, for this decoder -- so the four-byte fallback instantiations would otherwise never run.  A child process with
+    Q3_CODEC_H3_EPL=0 Q3_CODEC_EPL4=0 decodes the same 16-stream pass; same arithmetic per element, so the waveforms must be IDENTICAL (also checks the
+    pre-split operand form, Q3_CODEC_PRESPLIT=1, against the default within the 1e-6 its re-association allows)."""
+    import sys
+    path = os.path.join(full_model, "onnx", "q3tts_codec.gguf")
+    rng = np.random.default_rng(77)
+    codes = rng.integers(0, 2048, (16, 4, 16))
+    np.save(os.path.join(str(tmp_path), "codes.npy"), codes)
+    child = (
+        "import sys, numpy as np\n"
+        "sys.path.insert(0, %r)\n"
+        "import q3tts as Q\n"
+        "codes = np.load(sys.argv[1])\n"
+        "gd = Q.Decoder(%r, n_streams=16, max_frames=4, max_group=16)\n"
+        "[gd.reset(s) for s in range(16)]\n"
+        "np.save(sys.argv[2], gd.decode_group(list(range(16)), codes)); gd.close()\n"
+    ) % (os.path.join(ROOT, "qwen3-tts-rust_amd", "python"), path)
+    outs = {}
+    for name, env in (("default", {}), ("scalar", {"Q3_CODEC_H3_EPL": "0", "Q3_CODEC_EPL4": "0"}), ("presplit", {"Q3_CODEC_PRESPLIT": "1"})):
+        out = os.path.join(str(tmp_path), name + ".npy")
+        e = dict(os.environ); e.update(env)
+        r = subprocess.run([sys.executable, "-c", child, os.path.join(str(tmp_path), "codes.npy"), out], env=e, capture_output=True, text=True, timeout=300)
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[name] = np.load(out)
+    assert outs["default"].shape == (16, 4 * 1920) and np.isfinite(outs["default"]).all() and np.abs(outs["default"]).max() > 1e-3
+    assert np.array_equal(outs["default"], outs["scalar"])
+    assert np.sqrt(np.mean((outs["default"] - outs["presplit"]) ** 2)) < 1e-6
+
+
 @pytest.fixture(scope="module")
 def full_model_q5(synth_tool, full_model):
     marker = os.path.join(full_model, ".complete_q5_k_m")
