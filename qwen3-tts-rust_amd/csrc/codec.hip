@@ -867,6 +867,36 @@ __global__ void __launch_bounds__(256) k_conv_out_wave(const float* __restrict__
     a += bias;
     if (lane == 0) pcm[t] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
 }
+// Window form of the output convolution: a workgroup owns TB = 128 consecutive output samples of ONE segment (host guarantees segT % 128 == 0), copies their
+// 128 + 6 input rows into LDS once (16-byte loads: the one-wave-per-sample form fetched every row 7 times, 236 MB for a 94 MB input) and each wave
+// finishes 32 samples from there: lane l holds 3 float4 of the 7*C weights and reads the matching pieces of the sample's 7-row span.
+template <int C>
+__global__ void __launch_bounds__(256) k_conv_out_win(const float* __restrict__ in_ext, const float* __restrict__ w, float bias, float* __restrict__ pcm, int n, RowMap im) {
+    constexpr int TB = 128, ROWS = TB + 6, SPAN4 = 7 * C / 4, NW = (SPAN4 + 63) / 64;
+    __shared__ __attribute__((aligned(16))) float xs[ROWS * C];
+    const int t0 = blockIdx.x * TB, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const float* src = in_ext + map_row(im, t0) * C; // the TB samples of a block lie in one segment: their ROWS input rows are contiguous
+    for (int e = tid; e < ROWS * C / 4; e += 256) *reinterpret_cast<float4*>(xs + 4 * e) = *reinterpret_cast<const float4*>(src + 4 * e);
+    float4 wv[NW];
+#pragma unroll
+    for (int k = 0; k < NW; k++) { const int i = lane + 64 * k; wv[k] = i < SPAN4 ? *reinterpret_cast<const float4*>(w + 4 * i) : make_float4(0.f, 0.f, 0.f, 0.f); }
+    __syncthreads();
+    for (int j = 0; j < TB / 4; j++) {
+        const int tl = wave * (TB / 4) + j;
+        float a = 0.0f;
+#pragma unroll
+        for (int k = 0; k < NW; k++) {
+            const int i = lane + 64 * k;
+            if (i < SPAN4) {
+                const float4 x = *reinterpret_cast<const float4*>(xs + tl * C + 4 * i);
+                a += wv[k].x * x.x + wv[k].y * x.y + wv[k].z * x.z + wv[k].w * x.w;
+            }
+        }
+        for (int o = 32; o >= 1; o >>= 1) a += __shfl_xor(a, o);
+        a += bias;
+        if (lane == 0 && t0 + tl < n) pcm[t0 + tl] = a < -1.0f ? -1.0f : (a > 1.0f ? 1.0f : a);
+    }
+}
 // ---------------- host side ----------------
 struct ConvW { DevBuf<float> w, b; DevBuf<_Float16> wh, wl; int N = 0, K = 0, cin = 0, taps = 1, dil = 1; };
 struct Snake { DevBuf<float> ea, inv_eb; int C = 0; };
@@ -1369,6 +1399,9 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
     }
     // 8. output conv
     m.snake(st, m.snake_out, d, m.work(m.out_ext), G * T, m.cur_map(m.out_ext, T));
+    if (m.out_ext.C == 96 && T % 128 == 0) // (T = frames x 1920: every chunk length qualifies at the full decoder width)
+        hipLaunchKernelGGL((k_conv_out_win<96>), dim3(G * T / 128), dim3(256), 0, st, m.work(m.out_ext), m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T, m.base_map(m.out_ext, T));
+    else
     hipLaunchKernelGGL(k_conv_out_wave, dim3((G * T + 3) / 4), dim3(256), 0, st, m.work(m.out_ext), m.out_ext.C, m.conv_out_w.p, m.conv_out_b, m.S->pcm.p, G * T,
                        m.base_map(m.out_ext, T));
     m.move_hist(st, G, meta, true);
