@@ -733,27 +733,32 @@ __global__ void __launch_bounds__(256) k_layernorm_rows(const float* __restrict_
 }
 // per-call stream metadata on device: meta[0..G) = stream index, meta[G..2G) = valid K/V history rows, meta[2G..3G) = frames seen
 // NeoX RoPE on q and k inside a packed [G*T0][3*H] qkv buffer (head_dim hd), absolute position seen[g] + t
-__global__ void k_codec_rope(float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ cs, const float* __restrict__ sn,
-                             const int64_t* __restrict__ meta, int G, int T0, int max_pos) {
+// RoPE of q and k plus the K / V window append in one launch: thread e < H/2 rotates pair e of q (in place) and of k (in place and into the K window);
+// every thread also copies two V elements into the V window
+__global__ void k_codec_rope_append(float* __restrict__ qkv, int ld, int H, int hd, const float* __restrict__ cs, const float* __restrict__ sn,
+                                    const int64_t* __restrict__ meta, int G, int T0, int max_pos, float* __restrict__ kext, float* __restrict__ vext, RowMap om) {
     const int r = blockIdx.y, e = blockIdx.x * 256 + threadIdx.x, half = hd / 2;
     if (e >= H / 2) return;
     const int head = e / half, i = e % half;
     long long p = meta[2 * G + r / T0] + (r % T0);
     if (p >= max_pos) p = max_pos - 1;
     const float c = cs[(size_t)p * half + i], s = sn[(size_t)p * half + i];
-    for (int which = 0; which < 2; which++) {
-        float* v = qkv + (size_t)r * ld + which * H + head * hd;
+    const size_t o = map_row(om, r) * H;
+    float* row = qkv + (size_t)r * ld;
+    {
+        float* v = row + head * hd;
         const float a = v[i], b = v[i + half];
         v[i] = a * c - b * s; v[i + half] = b * c + a * s;
     }
-}
-// append new K,V rows to the batched K/V extended buffers (segment = (W-1) history rows + T0 new rows)
-__global__ void k_kv_append(const float* __restrict__ qkv, int ld, int H, float* __restrict__ kext, float* __restrict__ vext, RowMap om) {
-    const int r = blockIdx.y, c = blockIdx.x * 256 + threadIdx.x;
-    if (c >= H) return;
-    const size_t o = map_row(om, r) * H + c;
-    kext[o] = qkv[(size_t)r * ld + H + c];
-    vext[o] = qkv[(size_t)r * ld + 2 * H + c];
+    {
+        float* v = row + H + head * hd;
+        const float a = v[i], b = v[i + half];
+        const float x = a * c - b * s, y = b * c + a * s;
+        v[i] = x; v[i + half] = y;
+        kext[o + head * hd + i] = x; kext[o + head * hd + i + half] = y;
+    }
+    vext[o + e] = row[2 * H + e];
+    vext[o + e + H / 2] = row[2 * H + e + H / 2];
 }
 // sliding-window attention: one wave per (head, row); the segment of stream g holds its W-1 history rows RIGHT-aligned
 // (only the last kvlen[g] are valid) followed by the T0 new rows; keys of row t: max(t, W-1-kvlen) .. W-1+t
@@ -774,7 +779,12 @@ __global__ void __launch_bounds__(64) k_codec_attn(const float* __restrict__ qkv
     for (int jj = lane; jj < nk; jj += 64) {
         const float* kr = kext + (seg + j0 + jj) * H + head * hd;
         float a = 0.0f;
-        for (int d = 0; d < hd; d++) a += q_s[d] * kr[d];
+        if ((hd & 3) == 0) { // 16-byte loads of the lane's K row (rows start on hd-float boundaries); same order of adds
+            for (int d = 0; d < hd; d += 4) {
+                const float4 kk = *reinterpret_cast<const float4*>(kr + d);
+                a += q_s[d] * kk.x; a += q_s[d + 1] * kk.y; a += q_s[d + 2] * kk.z; a += q_s[d + 3] * kk.w;
+            }
+        } else for (int d = 0; d < hd; d++) a += q_s[d] * kr[d];
         a *= scale;
         p_s[jj] = a;
         mx = fmaxf(mx, a);
@@ -1337,9 +1347,8 @@ int CodecDecoder::decode_group_async(hipStream_t st, int G, const int* streams, 
         Ext &ke = m.k_ext[l], &ve = m.v_ext[l];
         hipLaunchKernelGGL(k_rmsnorm_rows, dim3(R0), dim3(256), 0, st, m.S->h.p, H, L.attn_norm.p, H, m.eps, m.S->xn.p, H);
         m.run_conv(st, L.wqkv, m.plain(m.S->xn.p), H, R0, m.plain(m.S->qkv.p), 3 * H, 3 * H);
-        hipLaunchKernelGGL(k_codec_rope, dim3((H / 2 + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
-                           meta, G, T0, m.max_pos);
-        hipLaunchKernelGGL(k_kv_append, dim3((H + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.work(ke), m.work(ve), m.cur_map(ke, T0));
+        hipLaunchKernelGGL(k_codec_rope_append, dim3((H / 2 + 255) / 256, R0), dim3(256), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.rope_c.p, m.rope_s.p,
+                           meta, G, T0, m.max_pos, m.work(ke), m.work(ve), m.cur_map(ke, T0));
         hipLaunchKernelGGL(k_codec_attn, dim3(m.n_heads, R0), dim3(64), 0, st, m.S->qkv.p, 3 * H, H, m.head_dim, m.work(ke), m.work(ve), meta, G, T0, W,
                            m.S->att.p, H);
         m.run_conv(st, L.wo, m.plain(m.S->att.p), H, R0, m.plain(m.S->h.p), H, H, EPI_RES_SCALE, m.plain(m.S->h.p), H, L.ls_attn.p);

@@ -205,7 +205,7 @@ const char* onnx_op_kernel(const std::string& op) {
         {"Transpose", "folded into GEMM addressing (time-major activations)"}, {"Reshape", "view"}, {"Unsqueeze", "view"}, {"Squeeze", "view"}, {"Cast", "load-time"},
         {"Clip", "k_conv_out_wave (final clamp)"}, {"Tanh", nullptr}, {"Where", "k_codec_attn (window mask)"}, {"Shape", "host"}, {"Constant", "host"},
         {"ConstantOfShape", "host"}, {"Expand", "view"}, {"Pad", "extended-buffer history rows"}, {"Sub", "k_layernorm_rows"}, {"Neg", "k_codec_rope"},
-        {"Cos", "k_codec_rope (tables built at load)"}, {"Range", "host"}, {"Equal", "host"}, {"Less", "k_codec_attn (window mask)"}, {"Identity", "view"},
+        {"Cos", "k_codec_rope_append (tables built at load)"}, {"Range", "host"}, {"Equal", "host"}, {"Less", "k_codec_attn (window mask)"}, {"Identity", "view"},
         // encoder-side ops that have no kernel in this engine yet (row a17)
         {"LSTM", nullptr}, {"GRU", nullptr}, {"Resize", nullptr}, {"InstanceNormalization", nullptr}, {"BatchNormalization", nullptr}, {"AveragePool", nullptr},
         {"GlobalAveragePool", nullptr}, {"Relu", nullptr}, {"LeakyRelu", nullptr}, {"Elu", nullptr}, {"ReduceSum", nullptr}, {"ArgMin", nullptr}, {"ArgMax", "k_argmax"},
