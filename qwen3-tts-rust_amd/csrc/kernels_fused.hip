@@ -742,37 +742,8 @@ void launch_attention_short(hipStream_t st, const float* qkv, int qkv_stride, in
 // ===================================================================================================
 // projection (assets_manager.rs:383-399 order preserved exactly)
 // ===================================================================================================
-// Blocked form: Wblk is [n_out/16][n_in][16] so a workgroup's 16 output columns are one contiguous slab that is
-// staged whole in LDS (n_in*64 B) by all 256 threads; 16 lanes then run the reference-ordered chains from LDS.
-__global__ void __launch_bounds__(256) k_project_blk(const float* __restrict__ x, int x_stride, const float* __restrict__ Wblk,
-                                                     const float* __restrict__ b, int n_in, int n_out, float* __restrict__ out,
-                                                     int out_stride) {
-    extern __shared__ __attribute__((aligned(16))) float sm[];
-    float* ws = sm;               // [n_in][16]
-    float* xs = sm + (size_t)n_in * 16;
-    const int ob = blockIdx.x, tok = blockIdx.y, tid = threadIdx.x;
-    const float4* src = reinterpret_cast<const float4*>(Wblk + (size_t)ob * n_in * 16);
-    float4* dst = reinterpret_cast<float4*>(ws);
-    for (int i = tid; i < n_in; i += 256) xs[i] = x[(size_t)tok * x_stride + i];
-    __syncthreads();
-    // the products x[i]*W[o][i] are independent roundings: all 256 threads form them while staging (t = x*w exactly as the reference's
-    // `x[i] * w[i]`), so the 16 serial chains below only add: sum = (((b + t0) + t1) + ...) in ascending i
-    for (int i = tid; i < n_in * 4; i += 256) {
-        float4 w = src[i];
-        const float xv = xs[i >> 2];
-        w.x = xv * w.x; w.y = xv * w.y; w.z = xv * w.z; w.w = xv * w.w;
-        dst[i] = w;
-    }
-    __syncthreads();
-    if (tid < 16) {
-        const int o = ob * 16 + tid;
-        float sum = b[o];
-#pragma unroll 16
-        for (int i = 0; i < n_in; i++) sum = sum + ws[i * 16 + tid];
-        out[(size_t)tok * out_stride + o] = sum;
-    }
-}
-// Many tokens: thread = one (token, output) chain (the reference's order: products added one by one in input order, no fma).  The chain is 2048
+// Wblk is [n_out/16][n_in][16]: a workgroup's 16 output columns are one contiguous slab.
+// Thread = one (token, output) chain (the reference's order: products added one by one in input order, no fma).  The chain is 2048
 // dependent adds; what made the first version slow (104 us at 64 tokens) was not the chain but 128 serialised batches of global weight loads behind it.
 // Now the workgroup's weight slab [n_in][16] and its 16 activation rows go through LDS in chunks of 512 inputs -- fetched with 16-byte loads one chunk
 // ahead (registers), stored transposed ([output][input], [token][input]; row stride 516 floats keeps the 16-byte reads of 16 rows on distinct banks) -- and
@@ -824,30 +795,12 @@ __global__ void __launch_bounds__(256) k_project_mt(const float* __restrict__ x,
     }
     if (t0 + tl < ntok) out[(size_t)(t0 + tl) * out_stride + o] = sum;
 }
-static bool g_attr_set[64] = {}, g_attr_mt[64] = {}; // the dynamic-LDS opt-in is per device
-// called once per device at engine construction, so that no attribute call happens inside a stream capture
-void init_fused_kernel_attributes() {
-    int dev = 0;
-    Q3_HIP(hipGetDevice(&dev));
-    if (dev < 0 || dev > 63) return;
-    if (!g_attr_set[dev]) { Q3_HIP(hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024)); g_attr_set[dev] = true; }
-}
+// (one kernel for every token count: at one token it replaced a 27.6 us single-workgroup-per-output-block form, C2 frame 2.816 -> 2.797 ms)
+void init_fused_kernel_attributes() {} // nothing needs a per-device opt-in any more (kept: the engine calls it before its first capture)
 void launch_project_blk(hipStream_t st, const float* x, int x_stride, const float* Wblk, const float* b, int n_in, int n_out,
                         float* out, int out_stride, int ntok) {
-    bool* attr_set = g_attr_set; bool* attr_mt = g_attr_mt;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    dev = dev < 0 || dev > 63 ? 0 : dev;
-    static const int mt_min = [] { const char* e = std::getenv("Q3_PROJECT_MT_MIN"); return e ? atoi(e) : 3; }(); // experiment knob
-    if (ntok >= mt_min) {
-        (void)attr_mt;
-        if (n_in % 512 != 0 || x_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) throw Error("k_project_mt: n_in must be a multiple of 512 and the rows 16-byte aligned");
-        hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), 0, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride, ntok);
-        return;
-    }
-    const size_t lds = (size_t)n_in * 17 * sizeof(float);
-    if (!attr_set[dev]) { (void)hipFuncSetAttribute((const void*)k_project_blk, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); attr_set[dev] = true; }
-    hipLaunchKernelGGL(k_project_blk, dim3(n_out / 16, ntok), dim3(256), lds, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride);
+    if (n_in % 512 != 0 || x_stride % 4 != 0 || (reinterpret_cast<uintptr_t>(x) & 15) != 0) throw Error("k_project_mt: n_in must be a multiple of 512 and the rows 16-byte aligned");
+    hipLaunchKernelGGL(k_project_mt, dim3(n_out / 16, (ntok + 15) / 16), dim3(256), 0, st, x, x_stride, Wblk, b, n_in, n_out, out, out_stride, ntok);
 }
 
 // ===================================================================================================
