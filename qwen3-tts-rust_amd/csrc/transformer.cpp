@@ -678,12 +678,14 @@ void KvPool::assign(int seq, int lp, int pp) {
 }
 void KvPool::ensure(int seq, int n_positions) {
     const int need = (n_positions + 63) / 64;
-    Q3_CHECK(need <= max_pages_, "sequence exceeds max pages");
+    Q3_CHECK(seq >= 0 && seq < n_seq_, "KV sequence index out of range");
+    Q3_CHECK(need <= max_pages_ && need <= n_pages_, "sequence exceeds max pages");
     while (used_pages_[seq] < need) { assign(seq, used_pages_[seq], alloc_page()); used_pages_[seq]++; }
 }
 void KvPool::ensure(int seq, int n_positions, hipStream_t st) {
     const int need = (n_positions + 63) / 64;
-    Q3_CHECK(need <= max_pages_, "sequence exceeds max pages");
+    Q3_CHECK(seq >= 0 && seq < n_seq_, "KV sequence index out of range");
+    Q3_CHECK(need <= max_pages_ && need <= n_pages_, "sequence exceeds max pages");
     const int first = used_pages_[seq];
     while (used_pages_[seq] < need) { table_[(size_t)seq * max_pages_ + used_pages_[seq]] = alloc_page(); used_pages_[seq]++; }
     if (need > first) // rows of other sequences are untouched, and this row is not rewritten before `st` is synchronised by the caller
@@ -692,6 +694,7 @@ void KvPool::ensure(int seq, int n_positions, hipStream_t st) {
 }
 KvPool::~KvPool() { if (table_) (void)hipHostFree(table_); }
 void KvPool::release(int seq) {
+    Q3_CHECK(seq >= 0 && seq < n_seq_, "KV sequence index out of range");
     for (int i = 0; i < used_pages_[seq]; i++) free_page(table_[(size_t)seq * max_pages_ + i]);
     used_pages_[seq] = 0;
 }
