@@ -784,11 +784,15 @@ k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
 #pragma unroll
                     for (int g = 0; g < 16; g++) red[wave][(g & 3) + 8 * (g >> 2) + 4 * half][r] = acc[g];
                 }
-                __syncthreads();
+                wg_barrier_lds(); // only LDS is shared here: __syncthreads() would also drain the loads and stores in flight (s_waitcnt vmcnt(0))
                 for (int t = threadIdx.x; t < 32 * 32; t += blockDim.x) { // whole 32-lane groups share a token (blockDim % 64 == 0)
                     const int m = t >> 5, rr = t & 31, tok = tok0 + m;
-                    float S = red[0][m][rr];
-                    for (int s2 = 1; s2 < nsg; s2++) S = S + red[s2][m][rr];
+                    float v8[8]; // all reads first, then the adds in segment order (a rolled loop pays one LDS round trip per add; rows s2 >= nsg are read and ignored)
+#pragma unroll
+                    for (int s2 = 0; s2 < 8; s2++) v8[s2] = red[s2][m][rr];
+                    float S = v8[0];
+#pragma unroll
+                    for (int s2 = 1; s2 < 8; s2++) S = (s2 < nsg) ? S + v8[s2] : S;
                     if (!GU) {
                         const int orow = blockIdx.x * 32 + rr;
                         if (orow < nrows && tok < ntok) out[((size_t)sseg * ntok + tok) * out_stride + orow] = S;
@@ -806,7 +810,7 @@ k_gemm_kq_mfma(Q8Mat w, int row0, int nrows, const int8_t* __restrict__ xq, cons
                         }
                     }
                 }
-                __syncthreads(); // red is rewritten by the next tile
+                wg_barrier_lds(); // red is rewritten by the next tile
             }
         }
     });
