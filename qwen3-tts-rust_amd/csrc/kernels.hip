@@ -1406,18 +1406,20 @@ __global__ void __launch_bounds__(512) __attribute__((amdgpu_waves_per_eu(2, 2))
                 dst[row * FM_PAD + (lane & 31)] = acc[v];
             }
         }
-        __syncthreads();
+        wg_barrier_lds(); // LDS only: a __syncthreads() also drains the weight / activation loads in flight (s_waitcnt vmcnt(0))
         const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
+        static_assert(Q3_SSEG_SEGS == 8, "segment combine below is unrolled for 8 segments");
 #pragma unroll
         for (int i = 0; i < 4; i++) {
-            float S = 0.0f;
-            for (int sg = 0; sg < nsl; sg++) {
-                const float a = segsum[((size_t)sg * 64 + orow) * FM_PAD + otok + 8 * i];
-                S = sg == 0 ? a : S + a;
-            }
+            float a8[8]; // all reads first, then the adds in segment order (a rolled loop pays one LDS round trip per add)
+#pragma unroll
+            for (int sg = 0; sg < 8; sg++) a8[sg] = segsum[((size_t)(sg < nsl ? sg : 0) * 64 + orow) * FM_PAD + otok + 8 * i];
+            float S = a8[0];
+#pragma unroll
+            for (int sg = 1; sg < 8; sg++) S = sg < nsl ? S + a8[sg] : S;
             y[i] = ss == 0 ? S : y[i] + S;
         }
-        __syncthreads();
+        wg_barrier_lds();
     }
     const int r = tile * 64 + orow;
 #pragma unroll
@@ -1484,14 +1486,18 @@ __global__ void __launch_bounds__(512) k_gemm_float_mfma16(const void* __restric
 #pragma unroll
             for (int r = 0; r < 4; r++) segsum[wave][4 * u + r][li] = acc[r];
         }
-        __syncthreads();
+        wg_barrier_lds();
         if (threadIdx.x < 256) {
             const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
-            float S = 0.0f;
-            for (int sg = 0; sg < nsl; sg++) { const float a = segsum[sg][orow][otok]; S = sg == 0 ? a : S + a; }
+            float a8[8];
+#pragma unroll
+            for (int sg = 0; sg < 8; sg++) a8[sg] = segsum[sg < nsl ? sg : 0][orow][otok];
+            float S = a8[0];
+#pragma unroll
+            for (int sg = 1; sg < 8; sg++) S = sg < nsl ? S + a8[sg] : S;
             y = ss == 0 ? S : y + S;
         }
-        __syncthreads();
+        wg_barrier_lds();
     }
     const int r = rt * 16 + orow, t = tok0 + otok;
     if (threadIdx.x < 256 && t < ntok && r < nrows) out[(size_t)t * out_stride + r] = y;
@@ -1559,17 +1565,18 @@ __global__ void __launch_bounds__(512) k_gateup_float_mfma16(const void* __restr
 #pragma unroll
             for (int r = 0; r < 4; r++) { segsum[0][wave][4 * u + r][li] = ag[r]; segsum[1][wave][4 * u + r][li] = au[r]; }
         }
-        __syncthreads();
+        wg_barrier_lds();
         if (threadIdx.x < 256) {
             const int nsl = nseg - ss * Q3_SSEG_SEGS < Q3_SSEG_SEGS ? nseg - ss * Q3_SSEG_SEGS : Q3_SSEG_SEGS;
-            float Sg = 0.0f, Su = 0.0f;
-            for (int sg = 0; sg < nsl; sg++) {
-                const float a = segsum[0][sg][orow][otok], c = segsum[1][sg][orow][otok];
-                Sg = sg == 0 ? a : Sg + a; Su = sg == 0 ? c : Su + c;
-            }
+            float g8[8], u8[8];
+#pragma unroll
+            for (int sg = 0; sg < 8; sg++) { g8[sg] = segsum[0][sg < nsl ? sg : 0][orow][otok]; u8[sg] = segsum[1][sg < nsl ? sg : 0][orow][otok]; }
+            float Sg = g8[0], Su = u8[0];
+#pragma unroll
+            for (int sg = 1; sg < 8; sg++) { Sg = sg < nsl ? Sg + g8[sg] : Sg; Su = sg < nsl ? Su + u8[sg] : Su; }
             yg = ss == 0 ? Sg : yg + Sg; yu = ss == 0 ? Su : yu + Su;
         }
-        __syncthreads();
+        wg_barrier_lds();
     }
     const int r = rt * 16 + orow, t = tok0 + otok;
     if (threadIdx.x < 256 && t < ntok && r < ff) act[(size_t)t * ff + r] = q3_swiglu(yg, yu);
