@@ -74,7 +74,8 @@ __device__ __forceinline__ void norm_quant_token(const NormPro& a, int d, int to
 // Workgroup-cooperative form of the same prologue (identical arithmetic): wave w fetches 256-chunk w (all global
 // loads of the token in ONE round trip instead of a serial chain in a single wave), wave 0 runs the spec's 64-lane
 // sum-of-squares chain over the chunks from LDS, then every wave scales + quantises its own chunk.
-// Requires blockDim.x == 64 * (d/256).  Contains __syncthreads(): all threads of the block must call it.
+// Requires blockDim.x == 64 * (d/256).  Contains a workgroup barrier: all threads of the block must call it; vbuf is read by EVERY wave after that
+// barrier, so a caller that reuses vbuf (a loop over tokens) puts a barrier between two calls.
 // ---------------------------------------------------------------------------------------------------
 __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, bool tok_valid, int lane, int wave, int8_t* xq_dst,
                                               uint16_t* xd_dst, float* vbuf, float* scal, bool write_global) {
@@ -105,7 +106,10 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
     }
     *reinterpret_cast<float4*>(vbuf + 256 * c + 4 * lane) = v;
     wg_barrier_lds();
-    if (wave == 0) {
+    // every wave runs the spec's 64-lane sum-of-squares chain itself (same order, same result in each wave): cheaper than wave 0 computing it
+    // and a second barrier + LDS round trip to hand the scale over
+    float scale;
+    {
         const int nch = d >> 8; // <= 8 (d <= 2048): all chunk reads first, then the chain in chunk order (a rolled loop pays an LDS round trip per chunk)
         float4 u[8];
 #pragma unroll
@@ -116,10 +120,9 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
             if (cc < nch) { p = q3_fmaf(u[cc].x, u[cc].x, p); p = q3_fmaf(u[cc].y, u[cc].y, p); p = q3_fmaf(u[cc].z, u[cc].z, p); p = q3_fmaf(u[cc].w, u[cc].w, p); }
         const float ss = wave_sum_bfly(p);
         const float mean = ss / (float)d;
-        if (lane == 0) scal[0] = 1.0f / q3_sqrtf(mean + a.eps);
+        scale = 1.0f / q3_sqrtf(mean + a.eps);
     }
-    wg_barrier_lds();
-    const float scale = scal[0];
+    (void)scal;
     float4 y;
     y.x = (v.x * scale) * g.x; y.y = (v.y * scale) * g.y; y.z = (v.z * scale) * g.z; y.w = (v.w * scale) * g.w;
     if (tok_valid && write_global && a.xn_out) *reinterpret_cast<float4*>(a.xn_out + (size_t)tok * d + 256 * c + 4 * lane) = y;
@@ -183,6 +186,7 @@ __global__ void __launch_bounds__(512) k_gemv_q8_norm(Q8Mat w, int row0, int nro
         for (int m = 0; m < MT; m++) { // (nwaves == K/256 by construction of the launch)
             const int tok = tok0 + m;
             norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
+            if (m + 1 < MT) wg_barrier_lds(); // every wave reads all of vbuf_s for its sum of squares: the next token may not overwrite it earlier
         }
         wg_barrier_lds();
         ws.finish(half);
@@ -290,6 +294,7 @@ __global__ void __launch_bounds__(64 * NSEG) k_gateup_swiglu(Q8Mat w, int ff, No
         for (int m = 0; m < MT; m++) {
             const int tok = tok0 + m;
             norm_quant_wg(a, w.K, tok, tok < ntok, lane, wave, xq_s[m], xd_s[m], vbuf_s, scal_s, blockIdx.x == 0);
+            if (m + 1 < MT) wg_barrier_lds(); // every wave reads all of vbuf_s for its sum of squares: the next token may not overwrite it earlier
         }
         wg_barrier_lds();
         wsg.finish(half); wsu.finish(half);
