@@ -139,19 +139,15 @@ __device__ __forceinline__ void norm_quant_wg(const NormPro& a, int d, int tok, 
 // standalone workgroup-per-token norm + quant (batched-step path): same arithmetic as k_rmsnorm_quant, one global
 // round trip instead of a serial chain in a single wave
 __global__ void __launch_bounds__(512) k_rmsnorm_quant_wg(NormPro a, int d, int8_t* __restrict__ xq, uint16_t* __restrict__ xd) {
-    __shared__ __attribute__((aligned(16))) int8_t xq_s[2048];
-    __shared__ __attribute__((aligned(16))) uint16_t xd_s[64];
     __shared__ __attribute__((aligned(16))) float vbuf_s[2048];
     __shared__ float scal_s[1];
     const int tok = blockIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     Q3_STAMP_DECL;
     Q3_STAMP(0);
-    norm_quant_wg(a, d, tok, true, lane, wave, xq_s, xd_s, vbuf_s, scal_s, true);
+    // the quantised row and its block scales go straight to global memory (a dword per lane = 256 contiguous bytes per wave): staging them in LDS for
+    // 16-byte stores cost a barrier and an LDS round trip that this latency-bound kernel does not get back
+    norm_quant_wg(a, d, tok, true, lane, wave, xq + (size_t)tok * d, xd + (size_t)tok * (d / 32), vbuf_s, scal_s, true);
     Q3_STAMP(1);
-    wg_barrier_lds();
-    for (int i = threadIdx.x; i < d / 16; i += blockDim.x)
-        *reinterpret_cast<uint4*>(xq + (size_t)tok * d + 16 * i) = *reinterpret_cast<const uint4*>(xq_s + 16 * i);
-    for (int i = threadIdx.x; i < d / 32; i += blockDim.x) xd[(size_t)tok * (d / 32) + i] = xd_s[i];
     Q3_STAMP(6);
     Q3_STAMP_FLUSH();
 }
